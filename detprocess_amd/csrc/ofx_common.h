@@ -1,0 +1,149 @@
+// ofx_common.h -- plan structures shared by the C ABI and the two engines.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ofx.h"
+
+#define OFX_SENTINEL (-999999.0f)
+
+void ofx_set_error(const char* fmt, ...);
+
+#define OFX_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            ofx_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,       \
+                          hipGetErrorString(e_));                              \
+            return OFX_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+#define OFX_FFT(expr)                                                          \
+    do {                                                                       \
+        rocfft_status s_ = (expr);                                             \
+        if (s_ != rocfft_status_success) {                                     \
+            ofx_set_error("%s:%d: %s -> rocfft status %d", __FILE__, __LINE__, \
+                          #expr, (int)s_);                                     \
+            return OFX_ERR_HIP;                                                \
+        }                                                                      \
+    } while (0)
+
+// ---------------------------------------------------------------- device view
+struct OfxSearchDev {
+    int kind;      // OFX_SEARCH_*
+    int lo, hi;    // half-open rolled range
+    int outside;   // search complement of [lo,hi)
+    int nlow;      // one-sided bins k = 0..nlow-1 have |f_k| <= lowchi2_fcutoff
+    int out_off;   // float offset of this search's record in the output row
+};
+
+struct OfxSlotDev {
+    const float2* wf;   // [K]   filter: A = C2R(wf * V)
+    const float* g;     // [K]   chi2 weights
+    const float2* s;    // [K]   template FFT (for lowchi2)
+    const float4* pq;   // [M]   fused engine: (P_k, Q_k) of the packed real-FFT filter
+    float norm;
+    float tres_sum;
+    float ampres;
+    int n_search;
+    OfxSearchDev search[OFX_MAX_SEARCHES];
+};
+
+struct OfxTdWinDev {
+    int lo, hi;     // end-exclusive slice
+    int out_off;
+};
+
+struct OfxPlanDev {
+    int N, K, pre;
+    float fs, inv_fs;
+    int row;                 // floats per output row
+    int n_channels, n_terms;
+    int chan[OFX_MAX_TERMS];
+    float weight[OFX_MAX_TERMS];
+    int n_tdwin;
+    OfxTdWinDev tdw[OFX_MAX_TDWIN];
+};
+
+// ------------------------------------------------------------------ host plan
+struct OfxSlotHost {
+    bool set = false;
+    float2* d_wf = nullptr;
+    float* d_g = nullptr;
+    float2* d_s = nullptr;
+    float4* d_pq = nullptr;
+    double norm = 0, tres_sum = 0;
+    std::vector<double> g_host;     // kept to count low-frequency bins
+    std::vector<OfxSearchDev> searches;
+};
+
+struct OfxFftPlans {
+    rocfft_plan r2c = nullptr, c2r = nullptr;
+    rocfft_execution_info info_r2c = nullptr, info_c2r = nullptr;
+    void* work = nullptr;
+    size_t work_bytes = 0;
+};
+
+struct ofx_plan {
+    int N = 0, K = 0, pre = 0;
+    double fs = 0;
+    int max_batch = 0;
+    int device = 0;
+    int engine = OFX_ENGINE_ROCFFT;
+    int n_channels = 1, n_terms = 1;
+    int chan[OFX_MAX_TERMS] = {0};
+    double weight[OFX_MAX_TERMS] = {1.0};
+    OfxSlotHost slot[OFX_MAX_SLOTS];
+    std::vector<OfxTdWinDev> tdwin;
+    int cu_count = 256;
+
+    // ROCFFT engine buffers (lazy)
+    std::map<int, OfxFftPlans> fft;      // keyed by batch
+    float* d_trace = nullptr;            // [max_batch, N] combined trace (if needed)
+    float2* d_spec = nullptr;            // [max_batch, K]
+    float2* d_filt = nullptr;            // [max_batch, K]
+    float* d_amp = nullptr;              // [max_batch, N]
+    float* d_chi0 = nullptr;             // [max_batch]
+    // staging for host buffers
+    float* d_stage_in = nullptr;
+    size_t stage_in_floats = 0;
+    uint8_t* d_stage_valid = nullptr;
+    float* d_stage_out = nullptr;
+    size_t stage_out_floats = 0;
+
+    // fused engine tables
+    float2* d_tw1 = nullptr;             // stage-1 inter-stage twiddles
+    float2* d_tw2 = nullptr;
+
+    // timing of the dominant kernel
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used = 0;
+    double t_acc_ms = 0;
+    long long t_launches = 0;
+};
+
+int ofx_row_floats(const ofx_plan* p);
+void ofx_fill_plan_dev(const ofx_plan* p, OfxPlanDev* d);
+void ofx_fill_slot_dev(const ofx_plan* p, int slot, OfxSlotDev* d);
+
+// engines
+int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
+                       long long n, float* d_out, hipStream_t st);
+int ofx_rocfft_release(ofx_plan* p);
+bool ofx_fused_supported(int n_samples);
+int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf);
+int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
+                      long long n, float* d_out, hipStream_t st);
+int ofx_fused_release(ofx_plan* p);
+
+// timing helpers
+int ofx_time_begin(ofx_plan* p, hipStream_t st, size_t* idx);
+int ofx_time_end(ofx_plan* p, hipStream_t st, size_t idx);

@@ -1,0 +1,163 @@
+// ofx_device.h -- device helpers shared by the ROCFFT and FUSED engines:
+// wave/block reductions, the arg-max candidate ordering, the low-frequency
+// chi2 residual sum and the output-record writer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ofx_common.h"
+
+#define OFX_WAVE 64
+
+// ------------------------------------------------------------- candidates
+// A candidate of the delay fit: key = A^2, rolled index i, amplitude A.
+// Ordering restates NumPy argmin(chi2) on the rolled array: larger A^2 wins
+// (chi2 = chi2_0 - A^2 norm), ties -> smaller rolled index.
+struct OfxCand {
+    float key;
+    int idx;
+    float amp;
+};
+
+__device__ __forceinline__ OfxCand ofx_cand_none() {
+    OfxCand c;
+    c.key = -1.0f;
+    c.idx = 0x7fffffff;
+    c.amp = 0.0f;
+    return c;
+}
+
+__device__ __forceinline__ bool ofx_cand_better(float key, int idx, const OfxCand& b) {
+    return (key > b.key) || (key == b.key && idx < b.idx);
+}
+
+__device__ __forceinline__ void ofx_cand_take(OfxCand& best, float amp, int idx) {
+    const float key = amp * amp;
+    if (ofx_cand_better(key, idx, best)) {
+        best.key = key;
+        best.idx = idx;
+        best.amp = amp;
+    }
+}
+
+__device__ __forceinline__ OfxCand ofx_cand_wave_reduce(OfxCand c) {
+#pragma unroll
+    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) {
+        const float k = __shfl_down(c.key, off, OFX_WAVE);
+        const int i = __shfl_down(c.idx, off, OFX_WAVE);
+        const float a = __shfl_down(c.amp, off, OFX_WAVE);
+        if (ofx_cand_better(k, i, c)) {
+            c.key = k;
+            c.idx = i;
+            c.amp = a;
+        }
+    }
+    return c;
+}
+
+// Block reduce; result valid in every thread.  scratch: >= (nthreads/64) OfxCand.
+__device__ __forceinline__ OfxCand ofx_cand_block_reduce(OfxCand c, OfxCand* scratch) {
+    const int lane = threadIdx.x & (OFX_WAVE - 1);
+    const int wave = threadIdx.x / OFX_WAVE;
+    const int nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
+    c = ofx_cand_wave_reduce(c);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = c;
+    __syncthreads();
+    OfxCand r = scratch[0];
+    for (int w = 1; w < nwave; ++w) {
+        const OfxCand o = scratch[w];
+        if (ofx_cand_better(o.key, o.idx, r)) r = o;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float ofx_wave_sum(float v) {
+#pragma unroll
+    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, OFX_WAVE);
+    return v;
+}
+__device__ __forceinline__ float ofx_wave_max(float v) {
+#pragma unroll
+    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, OFX_WAVE));
+    return v;
+}
+__device__ __forceinline__ float ofx_wave_min(float v) {
+#pragma unroll
+    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, OFX_WAVE));
+    return v;
+}
+
+// Block sum; result valid in every thread.  scratch: >= nthreads/64 floats.
+__device__ __forceinline__ float ofx_block_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & (OFX_WAVE - 1);
+    const int wave = threadIdx.x / OFX_WAVE;
+    const int nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
+    v = ofx_wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = 0.0f;
+    for (int w = 0; w < nwave; ++w) r += scratch[w];
+    return r;
+}
+__device__ __forceinline__ float ofx_block_max(float v, float* scratch) {
+    const int lane = threadIdx.x & (OFX_WAVE - 1);
+    const int wave = threadIdx.x / OFX_WAVE;
+    const int nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
+    v = ofx_wave_max(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int w = 1; w < nwave; ++w) r = fmaxf(r, scratch[w]);
+    return r;
+}
+__device__ __forceinline__ float ofx_block_min(float v, float* scratch) {
+    const int lane = threadIdx.x & (OFX_WAVE - 1);
+    const int wave = threadIdx.x / OFX_WAVE;
+    const int nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
+    v = ofx_wave_min(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float r = scratch[0];
+    for (int w = 1; w < nwave; ++w) r = fminf(r, scratch[w]);
+    return r;
+}
+
+// ------------------------------------------------------------ low-freq chi2
+// One term of  sum_{k < nlow} w_k g_k |V_k - A e^{-2 pi i k d / N} S_k|^2 ,
+// d = rolled index - pretrigger (integer lag), w_k = 1 at DC / Nyquist else 2
+// (one-sided evaluation of the two-sided sum; J symmetric, V and S Hermitian).
+__device__ __forceinline__ float ofx_lowchi2_term(int k, int N, int d, float amp,
+                                                  float2 V, float2 S, float g) {
+    long long m = ((long long)k * (long long)d) % (long long)N;
+    if (m < 0) m += N;
+    float sn, cs;
+    sincospif(-2.0f * (float)m / (float)N, &sn, &cs);
+    // ph * S
+    const float pr = cs * S.x - sn * S.y;
+    const float pi = cs * S.y + sn * S.x;
+    const float rr = V.x - amp * pr;
+    const float ri = V.y - amp * pi;
+    const float w = (k == 0 || 2 * k == N) ? 1.0f : 2.0f;
+    return w * g * (rr * rr + ri * ri);
+}
+
+// ----------------------------------------------------------- record writer
+__device__ __forceinline__ void ofx_write_search(float* row, const OfxSearchDev& q,
+                                                 const OfxSlotDev& sd, float inv_fs,
+                                                 int pre, float chi0, OfxCand best,
+                                                 float lowchi2) {
+    float* o = row + q.out_off;
+    const float amp = best.amp;
+    o[OFX_COL_AMP] = amp;
+    o[OFX_COL_T0] = (float)(best.idx - pre) * inv_fs;
+    o[OFX_COL_CHI2] = fmaf(-amp * amp, sd.norm, chi0);
+    o[OFX_COL_LOWCHI2] = lowchi2;
+    o[OFX_COL_CHI2NOPULSE] = chi0;
+    o[OFX_COL_AMPRES] = sd.ampres;
+    o[OFX_COL_TIMERES] = 1.0f / sqrtf(amp * amp * sd.tres_sum);
+    o[OFX_COL_INDEX] = (float)best.idx;
+}

@@ -1,0 +1,257 @@
+// ofx_rocfft.hip -- ROCFFT engine: the unfused pipeline named by north_star
+//   [prep/time-domain kernel] -> rocFFT R2C -> filter-apply + chi2_0 kernel
+//   -> rocFFT C2R -> arg-max / chi2 / lowchi2 kernel.
+// Handles any even trace length; the FUSED engine (ofx_fused.hip) replaces it
+// for the power-of-two lengths it supports.  Also the on-device cross-check of
+// the fused kernel in the GPU tests.
+#include "ofx_common.h"
+#include "ofx_device.h"
+
+#define RB 256   // threads per block in this file
+
+// ---------------------------------------------------------------------------
+// prep: channel algebra on load (processing_data.py:1033-1047) + time-domain
+// window features (algorithms.py:698, 759, 818, 879).  One block per event.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void k_prep(OfxPlanDev pd, const float* __restrict__ ev,
+                                             const uint8_t* __restrict__ valid,
+                                             float* __restrict__ combined,
+                                             float* __restrict__ out) {
+    __shared__ float scratch[RB / OFX_WAVE];
+    const long long b = blockIdx.x;
+    float* row = out + b * pd.row;
+    if (valid && !valid[b]) {
+        for (int w = threadIdx.x; w < pd.n_tdwin * OFX_TDWIN_FLOATS; w += RB)
+            row[pd.tdw[0].out_off + w] = OFX_SENTINEL;
+        return;
+    }
+    const float* e = ev + (size_t)b * pd.n_channels * pd.N;
+    float* c = combined ? combined + (size_t)b * pd.N : nullptr;
+
+    auto sample = [&](int n) -> float {
+        float v = pd.weight[0] * e[(size_t)pd.chan[0] * pd.N + n];
+        for (int j = 1; j < pd.n_terms; ++j)
+            v = fmaf(pd.weight[j], e[(size_t)pd.chan[j] * pd.N + n], v);
+        return v;
+    };
+    if (c)
+        for (int n = threadIdx.x; n < pd.N; n += RB) c[n] = sample(n);
+
+    for (int w = 0; w < pd.n_tdwin; ++w) {
+        const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+        float s = 0.0f, mx = -INFINITY, mn = INFINITY;
+        for (int n = lo + threadIdx.x; n < hi; n += RB) {
+            const float v = sample(n);
+            s += v;
+            mx = fmaxf(mx, v);
+            mn = fminf(mn, v);
+        }
+        s = ofx_block_sum(s, scratch);
+        mx = ofx_block_max(mx, scratch);
+        mn = ofx_block_min(mn, scratch);
+        if (threadIdx.x == 0) {
+            const float first = sample(lo), last = sample(hi - 1);
+            float* o = row + pd.tdw[w].out_off;
+            o[OFX_TD_BASELINE] = s / (float)(hi - lo);
+            o[OFX_TD_INTEGRAL] = (s - 0.5f * (first + last)) * pd.inv_fs;
+            o[OFX_TD_MAXIMUM] = mx;
+            o[OFX_TD_MINIMUM] = mn;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// filter apply: Y_k = wf_k V_k ; chi2_0 = sum_k w_k g_k |V_k|^2.  One block per
+// trace (OFBase.calc_signal_filt + chi2_0 -- processing_data.py:771).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void k_filter(int K, int N, const float2* __restrict__ wf,
+                                               const float* __restrict__ g,
+                                               const float2* __restrict__ spec,
+                                               float2* __restrict__ filt,
+                                               float* __restrict__ chi0) {
+    __shared__ float scratch[RB / OFX_WAVE];
+    const size_t b = blockIdx.x;
+    const float2* V = spec + b * K;
+    float2* Y = filt + b * K;
+    float acc = 0.0f;
+    for (int k = threadIdx.x; k < K; k += RB) {
+        const float2 v = V[k];
+        const float2 w = wf[k];
+        Y[k] = make_float2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
+        const float wt = (k == 0 || 2 * k == N) ? 1.0f : 2.0f;
+        acc = fmaf(wt * g[k], v.x * v.x + v.y * v.y, acc);
+    }
+    acc = ofx_block_sum(acc, scratch);
+    if (threadIdx.x == 0) chi0[b] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// search: arg-max of A^2 over the rolled window(s), chi2, low-frequency chi2,
+// record write.  One block per trace (qp.OF1x1.calc + get_result_* --
+// algorithms.py:336-341, 414-421, 538-558).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void k_search(OfxPlanDev pd, OfxSlotDev sd,
+                                               const float* __restrict__ amps,
+                                               const float2* __restrict__ spec,
+                                               const float* __restrict__ chi0v,
+                                               const uint8_t* __restrict__ valid,
+                                               float* __restrict__ out) {
+    __shared__ OfxCand cscratch[RB / OFX_WAVE];
+    __shared__ float scratch[RB / OFX_WAVE];
+    const size_t b = blockIdx.x;
+    float* row = out + b * pd.row;
+    if (valid && !valid[b]) {
+        for (int q = 0; q < sd.n_search; ++q)
+            for (int j = threadIdx.x; j < OFX_SEARCH_FLOATS; j += RB)
+                row[sd.search[q].out_off + j] = OFX_SENTINEL;
+        return;
+    }
+    const int N = pd.N, pre = pd.pre;
+    const float* a = amps + b * N;
+    const float2* V = spec + b * pd.K;
+    const float chi0 = chi0v[b];
+
+    for (int q = 0; q < sd.n_search; ++q) {
+        const OfxSearchDev sq = sd.search[q];
+        OfxCand best = ofx_cand_none();
+        auto scan = [&](int i0, int i1) {
+            for (int i = i0 + threadIdx.x; i < i1; i += RB) {
+                int n = i - pre;
+                if (n < 0) n += N;
+                ofx_cand_take(best, a[n], i);
+            }
+        };
+        if (sq.outside) {
+            scan(0, sq.lo);
+            scan(sq.hi, N);
+        } else {
+            scan(sq.lo, sq.hi);
+        }
+        best = ofx_cand_block_reduce(best, cscratch);
+        const int d = best.idx - pre;
+        float low = 0.0f;
+        for (int k = threadIdx.x; k < sq.nlow; k += RB)
+            low += ofx_lowchi2_term(k, N, d, best.amp, V[k], sd.s[k], sd.g[k]);
+        low = ofx_block_sum(low, scratch);
+        if (threadIdx.x == 0)
+            ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, low);
+    }
+}
+
+// ---------------------------------------------------------------------------
+static int get_fft(ofx_plan* p, int batch, hipStream_t st, OfxFftPlans** out) {
+    auto it = p->fft.find(batch);
+    if (it == p->fft.end()) {
+        static bool setup_done = false;
+        if (!setup_done) {
+            OFX_FFT(rocfft_setup());
+            setup_done = true;
+        }
+        OfxFftPlans f;
+        size_t len = (size_t)p->N;
+        OFX_FFT(rocfft_plan_create(&f.r2c, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_forward,
+                                   rocfft_precision_single, 1, &len, (size_t)batch, nullptr));
+        OFX_FFT(rocfft_plan_create(&f.c2r, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_inverse,
+                                   rocfft_precision_single, 1, &len, (size_t)batch, nullptr));
+        size_t w1 = 0, w2 = 0;
+        OFX_FFT(rocfft_plan_get_work_buffer_size(f.r2c, &w1));
+        OFX_FFT(rocfft_plan_get_work_buffer_size(f.c2r, &w2));
+        f.work_bytes = w1 > w2 ? w1 : w2;
+        if (f.work_bytes) OFX_HIP(hipMalloc(&f.work, f.work_bytes));
+        OFX_FFT(rocfft_execution_info_create(&f.info_r2c));
+        OFX_FFT(rocfft_execution_info_create(&f.info_c2r));
+        if (f.work_bytes) {
+            OFX_FFT(rocfft_execution_info_set_work_buffer(f.info_r2c, f.work, f.work_bytes));
+            OFX_FFT(rocfft_execution_info_set_work_buffer(f.info_c2r, f.work, f.work_bytes));
+        }
+        it = p->fft.emplace(batch, f).first;
+    }
+    OFX_FFT(rocfft_execution_info_set_stream(it->second.info_r2c, st));
+    OFX_FFT(rocfft_execution_info_set_stream(it->second.info_c2r, st));
+    *out = &it->second;
+    return OFX_OK;
+}
+
+int ofx_rocfft_release(ofx_plan* p) {
+    for (auto& kv : p->fft) {
+        OfxFftPlans& f = kv.second;
+        if (f.r2c) rocfft_plan_destroy(f.r2c);
+        if (f.c2r) rocfft_plan_destroy(f.c2r);
+        if (f.info_r2c) rocfft_execution_info_destroy(f.info_r2c);
+        if (f.info_c2r) rocfft_execution_info_destroy(f.info_c2r);
+        if (f.work) (void)hipFree(f.work);
+    }
+    p->fft.clear();
+    if (p->d_trace) (void)hipFree(p->d_trace);
+    if (p->d_spec) (void)hipFree(p->d_spec);
+    if (p->d_filt) (void)hipFree(p->d_filt);
+    if (p->d_amp) (void)hipFree(p->d_amp);
+    if (p->d_chi0) (void)hipFree(p->d_chi0);
+    p->d_trace = nullptr;
+    p->d_spec = p->d_filt = nullptr;
+    p->d_amp = p->d_chi0 = nullptr;
+    return OFX_OK;
+}
+
+int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
+                       long long n, float* d_out, hipStream_t st) {
+    const int N = p->N, K = p->K, MB = p->max_batch;
+    bool any_slot = false;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s)
+        if (p->slot[s].set && !p->slot[s].searches.empty()) any_slot = true;
+    const bool need_combine = p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0;
+    const bool need_prep = need_combine || !p->tdwin.empty();
+
+    if (any_slot && !p->d_spec) {
+        OFX_HIP(hipMalloc(&p->d_spec, sizeof(float2) * (size_t)MB * K));
+        OFX_HIP(hipMalloc(&p->d_filt, sizeof(float2) * (size_t)MB * K));
+        OFX_HIP(hipMalloc(&p->d_amp, sizeof(float) * (size_t)MB * N));
+        OFX_HIP(hipMalloc(&p->d_chi0, sizeof(float) * (size_t)MB));
+    }
+    if (need_combine && any_slot && !p->d_trace)
+        OFX_HIP(hipMalloc(&p->d_trace, sizeof(float) * (size_t)MB * N));
+
+    OfxPlanDev pd;
+    ofx_fill_plan_dev(p, &pd);
+
+    for (long long b0 = 0; b0 < n; b0 += MB) {
+        const int nb = (int)((n - b0 < MB) ? (n - b0) : MB);
+        const float* ev = d_traces + (size_t)b0 * p->n_channels * N;
+        const uint8_t* vld = d_valid ? d_valid + b0 : nullptr;
+        float* out = d_out + (size_t)b0 * pd.row;
+        const float* tr = ev;
+        if (need_prep) {
+            float* comb = (need_combine && any_slot) ? p->d_trace : nullptr;
+            hipLaunchKernelGGL(k_prep, dim3(nb), dim3(RB), 0, st, pd, ev, vld, comb, out);
+            if (comb) tr = comb;
+        }
+        if (!any_slot) continue;
+        OfxFftPlans* f = nullptr;
+        int rc = get_fft(p, nb, st, &f);
+        if (rc) return rc;
+        void* in1[1] = {(void*)tr};
+        void* out1[1] = {(void*)p->d_spec};
+        size_t tix = 0;
+        rc = ofx_time_begin(p, st, &tix);
+        if (rc) return rc;
+        OFX_FFT(rocfft_execute(f->r2c, in1, out1, f->info_r2c));
+        for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
+            if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
+            OfxSlotDev sd;
+            ofx_fill_slot_dev(p, s, &sd);
+            hipLaunchKernelGGL(k_filter, dim3(nb), dim3(RB), 0, st, K, N, sd.wf, sd.g,
+                               p->d_spec, p->d_filt, p->d_chi0);
+            void* in2[1] = {(void*)p->d_filt};
+            void* out2[1] = {(void*)p->d_amp};
+            OFX_FFT(rocfft_execute(f->c2r, in2, out2, f->info_c2r));
+            hipLaunchKernelGGL(k_search, dim3(nb), dim3(RB), 0, st, pd, sd, p->d_amp,
+                               p->d_spec, p->d_chi0, vld, out);
+        }
+        rc = ofx_time_end(p, st, tix);
+        if (rc) return rc;
+        OFX_HIP(hipGetLastError());
+    }
+    return OFX_OK;
+}

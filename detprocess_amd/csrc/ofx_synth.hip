@@ -1,0 +1,110 @@
+// ofx_synth.hip -- device-side synthetic event generator for bench.py and the
+// full-size GPU property tests (v = A * roll(template, d)
+// + noise; counter-based so any shard of a run is reproducible from
+// (seed, global trace index)).  Not part of the hot path.
+#include "ofx_common.h"
+
+struct Philox {
+    uint32_t c[4];
+    uint32_t k[2];
+};
+
+__device__ __forceinline__ void philox_round(uint32_t* c, const uint32_t* k) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0];
+    const uint32_t n1 = lo1;
+    const uint32_t n2 = hi0 ^ c[3] ^ k[1];
+    const uint32_t n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                           uint32_t k0, uint32_t k1, uint32_t* out) {
+    uint32_t c[4] = {c0, c1, c2, c3};
+    uint32_t k[2] = {k0, k1};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {      // (0,1]
+    return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
+}
+
+// one block per trace, 256 threads, 4 samples per thread per iteration
+__global__ __launch_bounds__(256) void k_synth(float* __restrict__ traces,
+                                               float* __restrict__ truth, long long first,
+                                               int N, const float* __restrict__ tmpl,
+                                               float sigma, float amp_lo, float amp_hi,
+                                               float pulse_fraction, int max_delay,
+                                               unsigned long long seed) {
+    const long long b = blockIdx.x;
+    const unsigned long long gid = (unsigned long long)(first + b);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t r[4];
+    philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), 0xFFFFFFFFu, 0u, k0, k1, r);
+    float amp = 0.0f;
+    if (u01(r[0]) <= pulse_fraction)
+        amp = amp_lo * expf(u01(r[1]) * logf(amp_hi / amp_lo));
+    int delay = 0;
+    if (max_delay > 0) delay = (int)(r[2] % (uint32_t)(2 * max_delay + 1)) - max_delay;
+    if (truth && threadIdx.x == 0) {
+        truth[2 * b] = amp;
+        truth[2 * b + 1] = (float)delay;
+    }
+    float* t = traces + (size_t)b * N;
+    for (int n4 = threadIdx.x; n4 < N / 4; n4 += 256) {
+        philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)n4, 1u, k0, k1, r);
+        float z[4];
+        {
+            const float r0 = sqrtf(-2.0f * logf(u01(r[0])));
+            float s, c;
+            sincospif(2.0f * u01(r[1]), &s, &c);
+            z[0] = r0 * c; z[1] = r0 * s;
+            const float r1 = sqrtf(-2.0f * logf(u01(r[2])));
+            sincospif(2.0f * u01(r[3]), &s, &c);
+            z[2] = r1 * c; z[3] = r1 * s;
+        }
+        float4 v;
+        float* pv = &v.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = 4 * n4 + j;
+            int src = n - delay;
+            if (src < 0) src += N;
+            if (src >= N) src -= N;
+            pv[j] = fmaf(amp, tmpl[src], sigma * z[j]);
+        }
+        *reinterpret_cast<float4*>(t + 4 * n4) = v;
+    }
+}
+
+extern "C" int ofx_synth_traces(float* traces, float* truth, long long n_traces,
+                                long long first_index, int n_samples,
+                                const float* template_td, float sigma, float amp_lo,
+                                float amp_hi, float pulse_fraction, int max_delay,
+                                unsigned long long seed, void* stream) {
+    if (!traces || !template_td || n_traces < 0 || n_samples < 4 || (n_samples & 3) ||
+        !(amp_lo > 0) || !(amp_hi >= amp_lo) || max_delay < 0 || max_delay >= n_samples) {
+        ofx_set_error("ofx_synth_traces: bad argument");
+        return OFX_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long maxgrid = 1 << 30;
+    for (long long b0 = 0; b0 < n_traces; b0 += maxgrid) {
+        const long long nb = (n_traces - b0 < maxgrid) ? (n_traces - b0) : maxgrid;
+        hipLaunchKernelGGL(k_synth, dim3((unsigned)nb), dim3(256), 0, st,
+                           traces + (size_t)b0 * n_samples,
+                           truth ? truth + 2 * b0 : nullptr, first_index + b0, n_samples,
+                           template_td, sigma, amp_lo, amp_hi, pulse_fraction, max_delay,
+                           seed);
+    }
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}

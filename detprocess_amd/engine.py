@@ -1,0 +1,218 @@
+"""OFPlan: Python handle on an ``ofx_plan`` (include/ofx.h).
+
+One plan = one ``(nb_samples, nb_pretrigger_samples)`` key of the reference's
+``_OF_base_objs`` dictionary (processing_data.py:274-286): a set of filter
+slots (template_tag x csd_tag), the of1x1 searches registered on each slot, the
+time-domain windows, and the channel algebra applied on load.  ``process``
+runs the whole hot path for a batch of events on the GPU and returns the
+feature matrix; it is the only compute entry and it has no CPU fallback.
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .filters import FilterTables
+
+_ENGINES = {"auto": _lib.ENGINE_AUTO, "fused": _lib.ENGINE_FUSED,
+            "rocfft": _lib.ENGINE_ROCFFT}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class OFPlan:
+    def __init__(self, n_samples, n_pretrigger, fs, max_batch=4096, device=0,
+                 engine="auto"):
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        self.n_samples = int(n_samples)
+        self.n_pretrigger = int(n_pretrigger)
+        self.fs = float(fs)
+        self.device = int(device)
+        self.n_channels = 1
+        _lib.check(self._lib.ofx_plan_create(C.byref(self._h), self.n_samples,
+                                             self.n_pretrigger, self.fs,
+                                             int(max_batch), self.device,
+                                             _ENGINES[engine]), "ofx_plan_create")
+        self.filters = {}
+
+    # ------------------------------------------------------------------ config
+    @property
+    def engine(self):
+        e = self._lib.ofx_plan_engine(self._h)
+        return {v: k for k, v in _ENGINES.items()}[e]
+
+    def set_filter(self, slot, tables: FilterTables):
+        if tables.n_samples != self.n_samples:
+            raise ValueError(f"ERROR: Number of samples is not consistent between "
+                             f"raw data (={self.n_samples}) and filter "
+                             f"(={tables.n_samples})")
+        wf = np.ascontiguousarray(tables.wf, dtype=np.complex128)
+        g = np.ascontiguousarray(tables.g, dtype=np.float64)
+        s = np.ascontiguousarray(tables.s, dtype=np.complex128)
+        _lib.check(self._lib.ofx_plan_set_filter(
+            self._h, int(slot), wf.ctypes.data, g.ctypes.data, s.ctypes.data,
+            float(tables.norm), float(tables.tres_sum)), "ofx_plan_set_filter")
+        self.filters[int(slot)] = tables
+
+    def add_search(self, slot, kind, lo=0, hi=None, outside=False,
+                   lowchi2_fcutoff=10000.0):
+        kind_i = {"nodelay": _lib.SEARCH_NODELAY, "delay": _lib.SEARCH_DELAY}[kind]
+        if hi is None:
+            hi = self.n_samples
+        sid = self._lib.ofx_plan_add_search(self._h, int(slot), kind_i, int(lo),
+                                            int(hi), int(bool(outside)),
+                                            float(lowchi2_fcutoff))
+        if sid < 0:
+            _lib.check(-sid, "ofx_plan_add_search")
+        return sid
+
+    def add_tdwindow(self, lo, hi):
+        wid = self._lib.ofx_plan_add_tdwindow(self._h, int(lo), int(hi))
+        if wid < 0:
+            _lib.check(-wid, "ofx_plan_add_tdwindow")
+        return wid
+
+    def set_channels(self, n_channels, chan_index, weights=None):
+        idx = np.ascontiguousarray(chan_index, dtype=np.int32)
+        w = np.ones(len(idx)) if weights is None else np.ascontiguousarray(
+            weights, dtype=np.float64)
+        _lib.check(self._lib.ofx_plan_set_channels(self._h, int(n_channels), len(idx),
+                                                   idx.ctypes.data, w.ctypes.data),
+                   "ofx_plan_set_channels")
+        self.n_channels = int(n_channels)
+
+    def reset(self):
+        _lib.check(self._lib.ofx_plan_reset(self._h), "ofx_plan_reset")
+        self.filters = {}
+        self.n_channels = 1
+
+    @property
+    def row_floats(self):
+        return self._lib.ofx_plan_row_floats(self._h)
+
+    def search_offset(self, slot, search):
+        return self._lib.ofx_plan_search_offset(self._h, int(slot), int(search))
+
+    def tdwindow_offset(self, window):
+        return self._lib.ofx_plan_tdwindow_offset(self._h, int(window))
+
+    # ----------------------------------------------------------------- timing
+    def enable_timing(self, on=True):
+        _lib.check(self._lib.ofx_plan_enable_timing(self._h, int(on)), "enable_timing")
+
+    def kernel_time(self):
+        ms = C.c_double()
+        n = C.c_longlong()
+        _lib.check(self._lib.ofx_plan_kernel_time(self._h, C.byref(ms), C.byref(n)),
+                   "ofx_plan_kernel_time")
+        return ms.value, n.value
+
+    # ---------------------------------------------------------------- compute
+    def process(self, traces, valid=None, out=None):
+        """Run the hot path on ``traces``.
+
+        traces: float32, shape [B, N] or [B, C, N]; a CUDA ``torch.Tensor``
+        (zero-copy, asynchronous on the current stream) or a NumPy array / CPU
+        tensor (staged over PCIe chunk by chunk).  valid: optional bool/uint8
+        [B]; rows with 0 come back as -999999.0.  Returns [B, row_floats]
+        float32 of the same kind as ``traces`` (or fills ``out``).
+        """
+        row = self.row_floats
+        is_np = isinstance(traces, np.ndarray)
+        if is_np:
+            if traces.dtype != np.float32 or not traces.flags["C_CONTIGUOUS"]:
+                traces = np.ascontiguousarray(traces, dtype=np.float32)
+            B = self._check_shape(traces.shape)
+            if out is None:
+                out = np.empty((B, row), dtype=np.float32)
+            v_ptr = None
+            if valid is not None:
+                valid = np.ascontiguousarray(valid, dtype=np.uint8)
+                v_ptr = valid.ctypes.data
+            _lib.check(self._lib.ofx_process(self._h, traces.ctypes.data, v_ptr, B,
+                                             _lib.MEM_HOST, out.ctypes.data,
+                                             _lib.MEM_HOST, None), "ofx_process")
+            return out
+        torch = _torch()
+        if not isinstance(traces, torch.Tensor):
+            raise TypeError("traces must be a numpy array or a torch tensor")
+        if not traces.is_cuda:
+            res = self.process(traces.numpy(), None if valid is None else
+                               np.asarray(valid), None)
+            return torch.from_numpy(res)
+        if traces.dtype != torch.float32:
+            raise TypeError("device traces must be float32")
+        if traces.device.index != self.device:
+            raise ValueError(f"traces live on cuda:{traces.device.index}, plan on "
+                             f"cuda:{self.device}")
+        traces = traces.contiguous()
+        B = self._check_shape(tuple(traces.shape))
+        if out is None:
+            out = torch.empty((B, row), dtype=torch.float32, device=traces.device)
+        v_ptr = None
+        if valid is not None:
+            valid = valid.to(device=traces.device, dtype=torch.uint8).contiguous()
+            v_ptr = valid.data_ptr()
+        stream = torch.cuda.current_stream(traces.device).cuda_stream
+        _lib.check(self._lib.ofx_process(self._h, traces.data_ptr(), v_ptr, B,
+                                         _lib.MEM_DEVICE, out.data_ptr(),
+                                         _lib.MEM_DEVICE, C.c_void_p(stream)),
+                   "ofx_process")
+        return out
+
+    def _check_shape(self, shape):
+        if len(shape) == 2:
+            if self.n_channels != 1:
+                raise ValueError("ERROR: traces must be [B, C, N] when channels are set")
+            B, n = shape
+        elif len(shape) == 3:
+            B, c, n = shape
+            if c != self.n_channels:
+                raise ValueError(f"ERROR: traces have {c} channels, plan expects "
+                                 f"{self.n_channels}")
+        else:
+            raise ValueError("ERROR: traces must be [B, N] or [B, C, N]")
+        if n != self.n_samples:
+            raise ValueError(f"ERROR: Number of samples is not consistent between "
+                             f"raw data (={n}) and plan (={self.n_samples})")
+        return int(B)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.ofx_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth_traces(n_traces, n_samples, template, sigma, amp_lo, amp_hi,
+                 pulse_fraction=0.5, max_delay=2000, seed=0, first_index=0,
+                 device=0, out=None, return_truth=True):
+    """Device-side synthetic events (ofx_synth_traces): returns (traces, truth)."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = torch.device("cuda", device)
+    if out is None:
+        out = torch.empty((n_traces, n_samples), dtype=torch.float32, device=dev)
+    truth = torch.empty((n_traces, 2), dtype=torch.float32, device=dev) \
+        if return_truth else None
+    t = torch.as_tensor(np.asarray(template, dtype=np.float32), device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.ofx_synth_traces(out.data_ptr(),
+                                    truth.data_ptr() if truth is not None else None,
+                                    int(n_traces), int(first_index), int(n_samples),
+                                    t.data_ptr(), float(sigma), float(amp_lo),
+                                    float(amp_hi), float(pulse_fraction),
+                                    int(max_delay), int(seed), C.c_void_p(stream)),
+               "ofx_synth_traces")
+    torch.cuda.current_stream(dev).synchronize()   # t must outlive the kernel
+    return out, truth

@@ -1,0 +1,181 @@
+/*
+ * ofx.h -- C ABI of libofx.so, the MI355X (gfx950) optimal-filter feature engine.
+ *
+ * This is the drop-in boundary for the per-event hot path of
+ * spice-herald/detprocess.  Nothing in the reference calls C (it is 100 %
+ * Python); each entry point below names the reference interface whose WORK it
+ * replaces.  The Python shim (detprocess_amd/_lib.py) binds exactly these
+ * symbols with ctypes; INTEGRATION.md shows the stub a detprocess maintainer
+ * would add.
+ *
+ * Conventions: status-int returns (0 = OFX_OK), no exceptions cross the ABI,
+ * caller-owned buffers, plain pointers and sizes, a plan is not thread-safe
+ * (one plan per stream).  Device pointers are HIP device pointers on the plan's
+ * device; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ */
+#ifndef OFX_H
+#define OFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ofx_plan ofx_plan;
+
+enum {
+    OFX_OK = 0,
+    OFX_ERR_ARG = 1,      /* bad argument (the reference raises ValueError) */
+    OFX_ERR_HIP = 2,      /* HIP runtime / rocFFT failure                   */
+    OFX_ERR_STATE = 3,    /* plan not fully configured                      */
+    OFX_ERR_UNSUPPORTED = 4
+};
+
+enum { OFX_MEM_HOST = 0, OFX_MEM_DEVICE = 1 };
+
+/* engines: FUSED = one persistent LDS-resident FFT kernel per trace
+ *          ROCFFT = rocFFT R2C -> filter kernel -> rocFFT C2R -> arg-max kernel
+ *          AUTO = FUSED where the trace length is supported, else ROCFFT     */
+enum { OFX_ENGINE_AUTO = 0, OFX_ENGINE_FUSED = 1, OFX_ENGINE_ROCFFT = 2 };
+
+/* search kinds (one per of1x1 algorithm instance) */
+enum {
+    OFX_SEARCH_NODELAY = 0,   /* algorithms.py:277-350  of1x1_nodelay        */
+    OFX_SEARCH_DELAY = 1      /* algorithms.py:354-432 / 435-570             */
+};
+
+#define OFX_MAX_SLOTS 8       /* (template_tag, csd_tag) filters per plan     */
+#define OFX_MAX_SEARCHES 8    /* of1x1 algorithm instances per filter slot    */
+#define OFX_MAX_TDWIN 8       /* baseline/integral/min/max windows per plan   */
+#define OFX_MAX_TERMS 8       /* channels combined by '+' / '-' on load       */
+
+/* per-search output record, floats, in this order */
+#define OFX_SEARCH_FLOATS 8
+enum {
+    OFX_COL_AMP = 0,          /* amp_<name>                                   */
+    OFX_COL_T0 = 1,           /* t0_<name>  [s]  ((index - pretrigger)/fs)    */
+    OFX_COL_CHI2 = 2,         /* chi2_<name>                                  */
+    OFX_COL_LOWCHI2 = 3,      /* lowchi2_<name>                               */
+    OFX_COL_CHI2NOPULSE = 4,  /* chi2nopulse_<name>                           */
+    OFX_COL_AMPRES = 5,       /* ampres_<name>  (constant of the filter)      */
+    OFX_COL_TIMERES = 6,      /* timeres_<name>                               */
+    OFX_COL_INDEX = 7         /* rolled bin index of the fit, as a float      */
+};
+/* per-time-domain-window output record, floats, in this order */
+#define OFX_TDWIN_FLOATS 4
+enum {
+    OFX_TD_BASELINE = 0,      /* algorithms.py:698  mean(trace[lo:hi])        */
+    OFX_TD_INTEGRAL = 1,      /* algorithms.py:759  trapz(trace[lo:hi])/fs    */
+    OFX_TD_MAXIMUM = 2,       /* algorithms.py:818                            */
+    OFX_TD_MINIMUM = 3        /* algorithms.py:879                            */
+};
+
+/* last error text of the calling thread ("" if none). */
+const char* ofx_last_error(void);
+
+/* library / device facts: fills "version;arch;cu_count" style text. */
+int ofx_device_info(int device, char* buf, size_t buflen);
+
+/*
+ * Create a plan for traces of n_samples at rate fs with n_pretrigger samples
+ * before the trigger.  Replaces qp.OFBase(sample_rate) construction keyed by
+ * (nb_samples, nb_pretrigger_samples, csd tag) --
+ * detprocess/process/processing_data.py:274-286.
+ * max_batch bounds the traces per ofx_process call chunk (work-buffer size for
+ * the ROCFFT engine; ignored by FUSED).
+ */
+int ofx_plan_create(ofx_plan** plan, int n_samples, int n_pretrigger, double fs,
+                    int max_batch, int device, int engine);
+int ofx_plan_destroy(ofx_plan* plan);
+
+/* which engine the plan resolved to (OFX_ENGINE_FUSED / OFX_ENGINE_ROCFFT). */
+int ofx_plan_engine(const ofx_plan* plan);
+
+/*
+ * Upload one precomputed optimal filter (host, fp64, one-sided K = n/2+1 bins).
+ * Replaces OFBase.set_csd + add_template + calc_phi --
+ * processing_data.py:321-326, 369-381 (the one-time precompute stays on the
+ * host; this call only rounds it to fp32 device tables).
+ *   wf[2K]   interleaved re,im of conj(S_k)/J_k/(N fs)/norm  -> A = C2R(wf*V)
+ *   g[K]     chi2 weights 1/(J_k N fs)   (0 where J = inf)
+ *   s[2K]    interleaved re,im of the template FFT S_k (NumPy, unnormalised)
+ *   norm, tres_sum: scalars of SURVEY.md Appendix A
+ */
+int ofx_plan_set_filter(ofx_plan* plan, int slot, const double* wf,
+                        const double* g, const double* s, double norm,
+                        double tres_sum);
+
+/*
+ * Register one of1x1 algorithm instance on a filter slot.  Replaces the
+ * per-event qp.OF1x1(...).calc(...) arguments -- algorithms.py:336-338,
+ * 414-418, 538-547.  [lo, hi) is the half-open range of ROLLED bin indices
+ * searched (outside != 0: its complement); ignored for OFX_SEARCH_NODELAY.
+ * Returns the search id (>= 0) or a negative error.
+ */
+int ofx_plan_add_search(ofx_plan* plan, int slot, int kind, int lo, int hi,
+                        int outside, double lowchi2_fcutoff);
+
+/*
+ * Register one time-domain window: baseline/integral/maximum/minimum of
+ * trace[lo:hi] (end-exclusive) -- algorithms.py:698, 759, 818, 879.
+ * Returns the window id (>= 0) or a negative error.
+ */
+int ofx_plan_add_tdwindow(ofx_plan* plan, int lo, int hi);
+
+/*
+ * Channel algebra on load: the processed trace is sum_j weight[j] *
+ * event[chan_index[j]] over the n_channels rows of each event.  Replaces
+ * ProcessingData.get_channel_trace -- processing_data.py:1033-1047.
+ * Default: n_channels = 1, one term (row 0, weight 1).
+ */
+int ofx_plan_set_channels(ofx_plan* plan, int n_channels, int n_terms,
+                          const int* chan_index, const double* weight);
+
+/* drop all filters / searches / windows (keeps buffers). */
+int ofx_plan_reset(ofx_plan* plan);
+
+/* floats per output row:  sum over slots of n_search*OFX_SEARCH_FLOATS,
+ * then n_tdwin*OFX_TDWIN_FLOATS.  Column offsets via the two calls below. */
+int ofx_plan_row_floats(const ofx_plan* plan);
+int ofx_plan_search_offset(const ofx_plan* plan, int slot, int search);
+int ofx_plan_tdwindow_offset(const ofx_plan* plan, int window);
+
+/*
+ * Process n_traces events.  traces: float32 [n_traces, n_channels, n_samples],
+ * contiguous.  valid: optional uint8 [n_traces] (same memory kind as traces);
+ * rows with valid == 0 are not processed and every column is -999999.0
+ * (algorithms.py:319-327, 398-407, 517-529, 683-688).  out: float32
+ * [n_traces, row_floats].  Replaces, per event, update_signal_OF
+ * (processing_data.py:712-772) and every FeatureExtractors.of1x1_* /
+ * baseline / integral / maximum / minimum call of features.py:692-851.
+ * Asynchronous on `stream` when both buffers are device memory.
+ */
+int ofx_process(ofx_plan* plan, const float* traces, const uint8_t* valid,
+                long long n_traces, int traces_mem, float* out, int out_mem,
+                void* stream);
+
+/*
+ * Device-side synthetic event generator (bench / tests): fills
+ * traces[n_traces, n_samples] with  amp_b * roll(template, delay_b) + sigma *
+ * white Gaussian noise, counter-based (seed, global trace index) so any shard
+ * of a run is reproducible.  amp/delay per trace are written to
+ * truth[n_traces, 2] if not NULL.  template_td: device float[n_samples].
+ */
+int ofx_synth_traces(float* traces, float* truth, long long n_traces,
+                     long long first_index, int n_samples,
+                     const float* template_td, float sigma, float amp_lo,
+                     float amp_hi, float pulse_fraction, int max_delay,
+                     unsigned long long seed, void* stream);
+
+/* average GPU time (ms) of the dominant kernel over the launches recorded since
+ * the last call, measured with HIP events on the launch stream; resets the
+ * accumulator.  n_launches receives the launch count. */
+int ofx_plan_kernel_time(ofx_plan* plan, double* avg_ms, long long* n_launches);
+int ofx_plan_enable_timing(ofx_plan* plan, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFX_H */
