@@ -80,6 +80,7 @@ struct OfxSlotHost {
     float2* d_s = nullptr;
     float4* d_pq = nullptr;
     double norm = 0, tres_sum = 0;
+    float wq_x = 0, wq_y = 0, gq = 0;   // fused engine: self-paired bin k = M/2
     std::vector<double> g_host;     // kept to count low-frequency bins
     std::vector<OfxSearchDev> searches;
 };

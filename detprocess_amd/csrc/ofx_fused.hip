@@ -1,7 +1,597 @@
-// ofx_fused.hip -- FUSED engine (placeholder until the LDS-resident FFT kernel lands)
+// ofx_fused.hip -- FUSED engine: one persistent workgroup per CU carries a whole
+// trace through   load -> real FFT -> optimal filter + chi2_0 -> inverse FFT ->
+// arg-max / chi2 / low-frequency chi2 -> one output row,
+// touching HBM once per sample.
+//
+// Geometry for N = 32768 real samples (M = N/2 = 16384 complex, z[m] = x[2m] +
+// i x[2m+1]):  512 threads x 32 complex values in VGPRs, M = 32 x 32 x 16.
+//   m = 512 n1 + 16 n2 + n3      k = k1 + 32 k2 + 1024 k3
+//   F1: thread t = n' = 16 n2 + n3, radix-32 over n1 -> k1, twiddle w_M^{n' k1}
+//   E1: LDS exchange D1[k1][n']            (row stride 513: conflict-free)
+//   F2: thread u = 32 n3 + k1, radix-32 over n2 -> k2, twiddle w_512^{n3 k2}
+//   E2: LDS exchange D2[k1 + 32 k2][n3]    (row stride 17: conflict-free)
+//   F3: thread v owns the two 16-point blocks k_low = v and its Hermitian
+//       partner 1024 - v (v = 0: the two self-paired blocks 0 and 512), so the
+//       real-FFT unpack, the filter multiply, chi2_0 and the re-pack for the
+//       inverse need NO exchange:  (Z_k, Z_{M-k}) live in the same thread.
+//   I3 / E3 / I2 / E4 / I1 mirror F3 / E2 / F2 / E1 / F1 with conjugate twiddles.
+// After I1 thread t holds A(n) for the 64 lags n = 1024 n1 + 2 t + {0,1}.
+#include <cmath>
+#include <cstring>
+
 #include "ofx_common.h"
-bool ofx_fused_supported(int) { return false; }
-int ofx_fused_prepare_slot(ofx_plan*, int, const double*) { return OFX_OK; }
-int ofx_fused_process(ofx_plan*, const float*, const uint8_t*, long long, float*, hipStream_t) {
-    ofx_set_error("FUSED engine not built"); return OFX_ERR_UNSUPPORTED; }
-int ofx_fused_release(ofx_plan*) { return OFX_OK; }
+#include "ofx_device.h"
+#include "ofx_fft_regs.h"
+
+using namespace ofxfft;
+
+namespace {
+
+constexpr int FN = 32768;          // samples
+constexpr int FM = 16384;          // packed complex points
+constexpr int FT = 512;            // threads
+constexpr int LD1 = 513;           // D1 row stride (float2)
+constexpr int LD2 = 17;            // D2 row stride (float2)
+constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 float2 >= 32*513, >= 16384
+constexpr int NLOW_MAX = 1024;
+constexpr int NWAVE = FT / OFX_WAVE;
+
+struct FusedLds {
+    float2 xbuf[XBUF_ELEMS];       // 139,264 B   exchange buffer / lag dump
+    float2 t2[512];                //   4,096 B   w_512^{n3 k2}, index k2*16+n3
+    float2 xlow[NLOW_MAX + 8];     //   8,256 B   2*X_k for k < 1024 (lowchi2)
+    float red[4][NWAVE];           // per-wave partials
+    unsigned long long bal[NWAVE];
+    OfxCand cand[NWAVE];
+    float bcast[8];
+};
+static_assert(sizeof(FusedLds) <= 160 * 1024, "LDS budget");
+
+struct FusedTabs {
+    const float2* t1;     // [32][512]  w_M^{n' k1}
+    const float2* t2;     // [32][16]   w_512^{n3 k2}
+    const float4* midA;   // [16][512]  (t_k.x, t_k.y, W_k.x/2, W_k.y/2)
+    const float4* midB;   // [16][512]  (conj(W_p).x/2, conj(W_p).y/2, g_k', g_p')
+    float2 wq;            // W_{M/2}  (the self-paired bin k = M/2)
+    float gq;             // g_{M/2}
+};
+
+__device__ __forceinline__ int partner_block(int v) { return v == 0 ? 512 : 1024 - v; }
+
+// ---- the pairwise middle step on one (Z_k, Z_p) slot -------------------------
+// in : zk = Z_k, zp = Z_p (p = M - k)      out: zk = Z'_k, zp = Z'_p
+// returns the chi2_0 contribution; xk2 = 2 X_k, xp2 = 2 conj(X_p).
+__device__ __forceinline__ float mid_slot(float2& zk, float2& zp, const float4 ta,
+                                          const float4 tb, float2& xk2, float2& xp2) {
+    const float2 t = make_float2(ta.x, ta.y);
+    const float2 wk = make_float2(ta.z, ta.w);
+    const float2 wp = make_float2(tb.x, tb.y);
+    const float2 u = make_float2(zk.x + zp.x, zk.y - zp.y);
+    const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
+    // s = i t w
+    const float2 s = make_float2(-fmaf(t.x, w.y, t.y * w.x), fmaf(t.x, w.x, -t.y * w.y));
+    xk2 = make_float2(u.x - s.x, u.y - s.y);
+    xp2 = make_float2(u.x + s.x, u.y + s.y);
+    float chi = tb.z * fmaf(xk2.x, xk2.x, xk2.y * xk2.y);
+    chi = fmaf(tb.w, fmaf(xp2.x, xp2.x, xp2.y * xp2.y), chi);
+    const float2 yk = cmul(xk2, wk);
+    const float2 yp = cmul(xp2, wp);
+    const float2 sg = make_float2(yk.x + yp.x, yk.y + yp.y);
+    const float2 df = make_float2(yk.x - yp.x, yk.y - yp.y);
+    // e = i conj(t) df
+    const float2 e = make_float2(-fmaf(t.x, df.y, -t.y * df.x), fmaf(t.x, df.x, t.y * df.y));
+    zk = make_float2(sg.x + e.x, sg.y + e.y);
+    zp = make_float2(sg.x - e.x, -(sg.y - e.y));
+    return chi;
+}
+
+__device__ __forceinline__ float2 sel(bool c, float2 a, float2 b) {
+    return make_float2(c ? a.x : b.x, c ? a.y : b.y);
+}
+
+// Middle step over the 32 values of a thread.  A = d[0..15] (block k_low = v),
+// B = d[16..31] (partner block).  Generic thread: slot j pairs (A[j], B[15-j]).
+// Thread 0 (blocks 0 and 512, both self-paired) is brought to the same slot
+// shape by a register permutation, applied only in the wave that holds it.
+template <bool WAVE0>
+__device__ __forceinline__ float middle(float2 (&d)[32], const FusedTabs& tabs, int v,
+                                        FusedLds& L) {
+    float2 a8 = d[8];
+    if constexpr (WAVE0) {
+        const bool z = (v == 0);
+        // genA = [A0[0..7], B0[0..7]] ; genB = [B0[8..15], A0[9..15], A0[0]]
+        float2 n[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) n[j] = d[j];
+#pragma unroll
+        for (int j = 8; j < 16; ++j) n[j] = sel(z, d[16 + j - 8], d[j]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[16 + 8 + i], d[16 + i]);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[(i + 1) % 16], d[16 + i]);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) d[j] = n[j];
+    }
+    float chi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 ta = tabs.midA[j * FT + v];
+        const float4 tb = tabs.midB[j * FT + v];
+        float2 xk2, xp2;
+        chi += mid_slot(d[j], d[16 + 15 - j], ta, tb, xk2, xp2);
+        if (j == 0) L.xlow[v] = xk2;                         // k = v (DC for v = 0)
+        if constexpr (WAVE0) {
+            if (j == 8 && v == 0) L.xlow[512] = xk2;          // thread 0: k = 512
+            if (j == 15 && v != 0) L.xlow[1024 - v] = make_float2(xp2.x, -xp2.y);
+        } else {
+            if (j == 15) L.xlow[1024 - v] = make_float2(xp2.x, -xp2.y);
+        }
+    }
+    if constexpr (WAVE0) {
+        const bool z = (v == 0);
+        // self-paired bin k = M/2 (thread 0, A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
+        const float2 zq = cmulc(a8, tabs.wq);
+        if (z) chi = fmaf(2.0f * tabs.gq, fmaf(a8.x, a8.x, a8.y * a8.y), chi);
+        // undo the permutation
+        float2 n[32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) n[j] = d[j];
+        // A0[8] special, A0[9..15] = genB[8..14], A0[0] = genA[0] (genB[15] discarded)
+        n[8] = sel(z, make_float2(2.0f * zq.x, 2.0f * zq.y), d[8]);
+#pragma unroll
+        for (int j = 9; j < 16; ++j) n[j] = sel(z, d[16 + j - 1], d[j]);
+        // B0[0..7] = genA[8..15] ; B0[8..15] = genB[0..7]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[8 + i], d[16 + i]);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[16 + i - 8], d[16 + i]);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) d[j] = n[j];
+    }
+    return chi;
+}
+
+// ------------------------------------------------------------------ the kernel
+// FEAT bit 0: plan has searches that are not full-range (scan the LDS lag dump)
+// FEAT bit 1: plan has time-domain windows
+template <int FEAT>
+__global__ __launch_bounds__(FT) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
+                                              const float* __restrict__ traces,
+                                              const uint8_t* __restrict__ valid,
+                                              long long n_traces, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    FusedLds& L = *reinterpret_cast<FusedLds*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n3u = tid >> 5, k1u = tid & 31;       // F2 / I2 role
+    const int kB = partner_block(tid);              // F3 / I3 role
+
+    for (int i = tid; i < 512; i += FT) L.t2[i] = tabs.t2[i];
+    __syncthreads();
+
+    const size_t ev_stride = (size_t)pd.n_channels * FN;
+    float2 d[32];
+    float2 pf[32];
+    long long b = blockIdx.x;
+
+    auto load_trace = [&](long long bb, float2 (&dst)[32]) {
+        const float* e = traces + (size_t)bb * ev_stride;
+        if (pd.n_terms == 1 && pd.weight[0] == 1.0f) {
+            const float2* z = reinterpret_cast<const float2*>(e + (size_t)pd.chan[0] * FN);
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) dst[n1] = z[512 * n1 + tid];
+        } else {
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1) dst[n1] = make_float2(0.f, 0.f);
+            for (int j = 0; j < pd.n_terms; ++j) {
+                const float2* z = reinterpret_cast<const float2*>(e + (size_t)pd.chan[j] * FN);
+                const float wgt = pd.weight[j];
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    const float2 s = z[512 * n1 + tid];
+                    dst[n1].x = fmaf(wgt, s.x, dst[n1].x);
+                    dst[n1].y = fmaf(wgt, s.y, dst[n1].y);
+                }
+            }
+        }
+    };
+
+    if (b < n_traces) load_trace(b, pf);
+
+    for (; b < n_traces; b += gridDim.x) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) d[j] = pf[j];
+        const long long bn = b + gridDim.x;
+        float* row = out + (size_t)b * pd.row;
+        const bool ok = !(valid && !valid[b]);
+        if (!ok) {
+            if (bn < n_traces) load_trace(bn, pf);
+            for (int j = tid; j < pd.row; j += FT) row[j] = OFX_SENTINEL;
+            continue;
+        }
+
+        // ------------------------------------------------ time-domain windows
+        if constexpr (FEAT & 2) {
+            for (int w = 0; w < pd.n_tdwin; ++w) {
+                const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+                float s = 0.0f, mx = -INFINITY, mn = INFINITY, fl = 0.0f;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    const int n = 1024 * n1 + 2 * tid;
+                    const bool in0 = (n >= lo) && (n < hi);
+                    const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                    const float x0 = d[n1].x, x1 = d[n1].y;
+                    s += (in0 ? x0 : 0.0f) + (in1 ? x1 : 0.0f);
+                    mx = fmaxf(mx, fmaxf(in0 ? x0 : -INFINITY, in1 ? x1 : -INFINITY));
+                    mn = fminf(mn, fminf(in0 ? x0 : INFINITY, in1 ? x1 : INFINITY));
+                    if (n == lo || n == hi - 1) fl += x0;
+                    if (n + 1 == lo || n + 1 == hi - 1) fl += x1;
+                }
+                if (hi - lo == 1) fl *= 2.0f;          // first == last sample
+                s = ofx_wave_sum(s);
+                mx = ofx_wave_max(mx);
+                mn = ofx_wave_min(mn);
+                fl = ofx_wave_sum(fl);
+                __syncthreads();
+                if (lane == 0) {
+                    L.red[0][wave] = s; L.red[1][wave] = mx;
+                    L.red[2][wave] = mn; L.red[3][wave] = fl;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    float S = 0.f, MX = -INFINITY, MN = INFINITY, FLs = 0.f;
+                    for (int q = 0; q < NWAVE; ++q) {
+                        S += L.red[0][q]; MX = fmaxf(MX, L.red[1][q]);
+                        MN = fminf(MN, L.red[2][q]); FLs += L.red[3][q];
+                    }
+                    float* o = row + pd.tdw[w].out_off;
+                    o[OFX_TD_BASELINE] = S / (float)(hi - lo);
+                    o[OFX_TD_INTEGRAL] = (S - 0.5f * FLs) * pd.inv_fs;
+                    o[OFX_TD_MAXIMUM] = MX;
+                    o[OFX_TD_MINIMUM] = MN;
+                }
+            }
+        }
+        if (sd.n_search == 0) {
+            if (bn < n_traces) load_trace(bn, pf);
+            continue;
+        }
+
+        // ---------------------------------------------------------------- F1
+        dft<32, -1>(d);
+        {
+            float2 tw[32];
+#pragma unroll
+            for (int k1 = 1; k1 < 32; ++k1) tw[k1] = tabs.t1[k1 * 512 + tid];
+            // prefetch the next trace behind the twiddle loads (vmcnt is in-order)
+            if (bn < n_traces) load_trace(bn, pf);
+#pragma unroll
+            for (int k1 = 1; k1 < 32; ++k1) d[k1] = cmul(d[k1], tw[k1]);
+        }
+        __syncthreads();                       // previous trace's LDS readers are done
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) L.xbuf[k1 * LD1 + tid] = d[k1];
+        __syncthreads();
+        // ---------------------------------------------------------------- F2
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) d[n2] = L.xbuf[k1u * LD1 + 16 * n2 + n3u];
+        dft<32, -1>(d);
+#pragma unroll
+        for (int k2 = 1; k2 < 32; ++k2) d[k2] = cmul(d[k2], L.t2[k2 * 16 + n3u]);
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) L.xbuf[(k1u + 32 * k2) * LD2 + n3u] = d[k2];
+        __syncthreads();
+        // ---------------------------------------------------------------- F3
+#pragma unroll
+        for (int n3 = 0; n3 < 16; ++n3) {
+            d[n3] = L.xbuf[tid * LD2 + n3];
+            d[16 + n3] = L.xbuf[kB * LD2 + n3];
+        }
+        dft<16, -1, 32, 0>(d);
+        dft<16, -1, 32, 16>(d);
+        // ------------------------------------------------------------ middle
+        float chi0p;
+        if (wave == 0) chi0p = middle<true>(d, tabs, tid, L);
+        else chi0p = middle<false>(d, tabs, tid, L);
+        // ---------------------------------------------------------------- I3
+        dft<16, +1, 32, 0>(d);
+        dft<16, +1, 32, 16>(d);
+        __syncthreads();
+#pragma unroll
+        for (int n3 = 0; n3 < 16; ++n3) {
+            L.xbuf[tid * LD2 + n3] = d[n3];
+            L.xbuf[kB * LD2 + n3] = d[16 + n3];
+        }
+        __syncthreads();
+        // ---------------------------------------------------------------- I2
+#pragma unroll
+        for (int k2 = 0; k2 < 32; ++k2) d[k2] = L.xbuf[(k1u + 32 * k2) * LD2 + n3u];
+#pragma unroll
+        for (int k2 = 1; k2 < 32; ++k2) d[k2] = cmulc(d[k2], L.t2[k2 * 16 + n3u]);
+        dft<32, +1>(d);
+        __syncthreads();
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) L.xbuf[k1u * LD1 + 16 * n2 + n3u] = d[n2];
+        __syncthreads();
+        // ---------------------------------------------------------------- I1
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) d[k1] = L.xbuf[k1 * LD1 + tid];
+#pragma unroll
+        for (int k1 = 1; k1 < 32; ++k1) d[k1] = cmulc(d[k1], tabs.t1[k1 * 512 + tid]);
+        dft<32, +1>(d);
+        // d[n1] = (A(1024 n1 + 2 tid), A(1024 n1 + 2 tid + 1))
+
+        // ------------------------------------------------------------- tail
+        float mloc = 0.0f;
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1)
+            mloc = fmaxf(mloc, fmaxf(d[n1].x * d[n1].x, d[n1].y * d[n1].y));
+        const float wmax = ofx_wave_max(mloc);
+        const float wchi = ofx_wave_sum(chi0p);
+        __syncthreads();                       // every E4 read is done -> dump lags
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) L.xbuf[512 * n1 + tid] = d[n1];
+        if (lane == 0) {
+            L.red[0][wave] = wmax;
+            L.red[1][wave] = wchi;
+        }
+        __syncthreads();
+        const float* alag = reinterpret_cast<const float*>(L.xbuf);   // A(n), natural lag order
+        float Mstar = L.red[0][0], chi0 = L.red[1][0];
+#pragma unroll
+        for (int q = 1; q < NWAVE; ++q) {
+            Mstar = fmaxf(Mstar, L.red[0][q]);
+            chi0 += L.red[1][q];
+        }
+        // threads whose local maximum equals the global one
+        {
+            const unsigned long long bm = __ballot(mloc == Mstar);
+            if (lane == 0) L.bal[wave] = bm;
+        }
+        __syncthreads();
+
+        const int pre = pd.pre;
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev sq = sd.search[q];
+            OfxCand best;
+            const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
+                              sq.hi == FN;
+            if (sq.kind == OFX_SEARCH_NODELAY) {
+                best.amp = alag[0];
+                best.idx = pre;
+                best.key = best.amp * best.amp;
+            } else if (full) {
+                // wave 0 resolves the smallest rolled index among lags with A^2 == Mstar
+                if (wave == 0) {
+                    int bi = 0x7fffffff;
+                    for (int w = 0; w < NWAVE; ++w) {
+                        unsigned long long bm = L.bal[w];
+                        while (bm) {
+                            const int bit = __ffsll((long long)bm) - 1;
+                            bm &= bm - 1;
+                            const int ts = w * 64 + bit;
+                            const int n = 1024 * (lane >> 1) + 2 * ts + (lane & 1);
+                            const float a = alag[n];
+                            const int ri = (n + pre) & (FN - 1);
+                            int c = (a * a == Mstar) ? ri : 0x7fffffff;
+#pragma unroll
+                            for (int off = 32; off > 0; off >>= 1)
+                                c = min(c, __shfl_xor(c, off, 64));
+                            bi = min(bi, c);
+                        }
+                    }
+                    if (lane == 0) {
+                        L.bcast[0] = __int_as_float(bi);
+                        L.bcast[1] = alag[(bi - pre) & (FN - 1)];
+                    }
+                }
+                __syncthreads();
+                best.idx = __float_as_int(L.bcast[0]);
+                best.amp = L.bcast[1];
+                best.key = Mstar;
+                __syncthreads();
+            } else {
+                best = ofx_cand_none();
+                if constexpr (FEAT & 1) {
+                    auto scan = [&](int i0, int i1) {
+                        for (int i = i0 + tid; i < i1; i += FT)
+                            ofx_cand_take(best, alag[(i - pre) & (FN - 1)], i);
+                    };
+                    if (sq.outside) {
+                        scan(0, sq.lo);
+                        scan(sq.hi, FN);
+                    } else {
+                        scan(sq.lo, sq.hi);
+                    }
+                    best = ofx_cand_block_reduce(best, L.cand);
+                }
+            }
+            // low-frequency chi2 at (amp, t0)
+            const int dl = best.idx - pre;
+            float low = 0.0f;
+            for (int k = tid; k < sq.nlow; k += FT) {
+                const float2 x2 = L.xlow[k];
+                low += ofx_lowchi2_term(k, FN, dl, best.amp,
+                                        make_float2(0.5f * x2.x, 0.5f * x2.y), sd.s[k], sd.g[k]);
+            }
+            low = ofx_wave_sum(low);
+            __syncthreads();
+            if (lane == 0) L.red[2][wave] = low;
+            __syncthreads();
+            if (tid == 0) {
+                float lw = 0.0f;
+                for (int w = 0; w < NWAVE; ++w) lw += L.red[2][w];
+                ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, lw);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// =============================================================== host side
+bool ofx_fused_supported(int n_samples) { return n_samples == FN; }
+
+int ofx_fused_release(ofx_plan* p) {
+    if (p->d_tw1) (void)hipFree(p->d_tw1);
+    if (p->d_tw2) (void)hipFree(p->d_tw2);
+    p->d_tw1 = p->d_tw2 = nullptr;
+    return OFX_OK;
+}
+
+static int fused_tables(ofx_plan* p) {
+    if (p->d_tw1) return OFX_OK;
+    const double PI2 = 6.283185307179586476925286766559;
+    std::vector<float2> t1(32 * 512), t2(32 * 16);
+    for (int k1 = 0; k1 < 32; ++k1)
+        for (int n = 0; n < 512; ++n) {
+            const long long e = ((long long)k1 * n) % FM;
+            const double a = -PI2 * (double)e / FM;
+            t1[k1 * 512 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k2 = 0; k2 < 32; ++k2)
+        for (int n3 = 0; n3 < 16; ++n3) {
+            const int e = (k2 * n3) % 512;
+            const double a = -PI2 * (double)e / 512.0;
+            t2[k2 * 16 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    OFX_HIP(hipMalloc(&p->d_tw1, sizeof(float2) * t1.size()));
+    OFX_HIP(hipMalloc(&p->d_tw2, sizeof(float2) * t2.size()));
+    OFX_HIP(hipMemcpy(p->d_tw1, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
+    OFX_HIP(hipMemcpy(p->d_tw2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+    return OFX_OK;
+}
+
+// Build the middle-step tables of one slot from the fp64 one-sided filter.
+//   d_pq layout: [0 .. 16*512)        midA (t_k, W_k/2)
+//                [16*512 .. 2*16*512) midB (conj(W_p)/2, g_k', g_p')
+//                [2*16*512]           (W_{M/2}.x, W_{M/2}.y, g_{M/2}, 0)
+int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
+    int rc = fused_tables(p);
+    if (rc) return rc;
+    OfxSlotHost& h = p->slot[slot];
+    const double PI2 = 6.283185307179586476925286766559;
+    const std::vector<double>& g = h.g_host;
+    std::vector<float4> tab(2 * 16 * FT + 1);
+    auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
+    for (int v = 0; v < FT; ++v) {
+        for (int j = 0; j < 16; ++j) {
+            int k;
+            if (v != 0) k = v + 1024 * j;
+            else k = (j < 8) ? 1024 * j : 512 + 1024 * (j - 8);
+            const int pidx = (FM - k) % FM;
+            double wkr, wki, wpr, wpi, gk, gp;
+            if (k == 0) {
+                // slot (DC, Nyquist): "p" is the Nyquist bin N/2 = M
+                W(0, wkr, wki);
+                W(FM, wpr, wpi);
+                gk = g[0] / 4.0;
+                gp = g[FM] / 4.0;
+            } else {
+                W(k, wkr, wki);
+                W(pidx, wpr, wpi);
+                gk = g[k] / 2.0;
+                gp = g[pidx] / 2.0;
+            }
+            const double a = -PI2 * (double)k / FN;
+            tab[j * FT + v] = make_float4((float)std::cos(a), (float)std::sin(a),
+                                          (float)(wkr / 2.0), (float)(wki / 2.0));
+            tab[16 * FT + j * FT + v] =
+                make_float4((float)(wpr / 2.0), (float)(-wpi / 2.0), (float)gk, (float)gp);
+        }
+    }
+    tab[2 * 16 * FT] = make_float4((float)wf[2 * (FM / 2)], (float)wf[2 * (FM / 2) + 1],
+                                   (float)g[FM / 2], 0.0f);
+    h.wq_x = tab[2 * 16 * FT].x;
+    h.wq_y = tab[2 * 16 * FT].y;
+    h.gq = tab[2 * 16 * FT].z;
+    OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
+    OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
+    return OFX_OK;
+}
+
+template <int FEAT>
+static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const FusedTabs& tabs,
+                  const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                  hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)sizeof(FusedLds)));
+        attr_set = true;
+    }
+    long long grid = p->cu_count;
+    if (grid > n) grid = n;
+    size_t tix = 0;
+    int rc = ofx_time_begin(p, st, &tix);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fused<FEAT>, dim3((unsigned)grid), dim3(FT), sizeof(FusedLds), st, pd,
+                       sd, tabs, d_traces, d_valid, n, d_out);
+    rc = ofx_time_end(p, st, tix);
+    if (rc) return rc;
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
+                      float* d_out, hipStream_t st) {
+    OfxPlanDev pd;
+    ofx_fill_plan_dev(p, &pd);
+    int nslots = 0;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s)
+        if (p->slot[s].set && !p->slot[s].searches.empty()) ++nslots;
+    bool first = true;
+    for (int s = 0; s < OFX_MAX_SLOTS || first; ++s) {
+        OfxSlotDev sd;
+        memset(&sd, 0, sizeof(sd));
+        FusedTabs tabs;
+        memset(&tabs, 0, sizeof(tabs));
+        if (nslots > 0) {
+            if (s >= OFX_MAX_SLOTS) break;
+            if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
+            ofx_fill_slot_dev(p, s, &sd);
+            int rc = fused_tables(p);
+            if (rc) return rc;
+            tabs.t1 = p->d_tw1;
+            tabs.t2 = p->d_tw2;
+            tabs.midA = p->slot[s].d_pq;
+            tabs.midB = p->slot[s].d_pq + 16 * FT;
+            tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
+            tabs.gq = p->slot[s].gq;
+        } else {
+            int rc = fused_tables(p);
+            if (rc) return rc;
+            tabs.t1 = p->d_tw1;
+            tabs.t2 = p->d_tw2;
+        }
+        // time-domain windows ride on the first launch only
+        OfxPlanDev pdl = pd;
+        if (!first) pdl.n_tdwin = 0;
+        int feat = 0;
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev& sq = sd.search[q];
+            if (sq.kind == OFX_SEARCH_DELAY &&
+                !(sq.lo == 0 && sq.hi == p->N && !sq.outside))
+                feat |= 1;
+            if (sq.nlow > NLOW_MAX) {
+                ofx_set_error("FUSED engine: lowchi2_fcutoff covers %d bins (> %d)", sq.nlow,
+                              NLOW_MAX);
+                return OFX_ERR_UNSUPPORTED;
+            }
+        }
+        if (pdl.n_tdwin > 0) feat |= 2;
+        int rc;
+        switch (feat) {
+            case 0: rc = launch<0>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            case 1: rc = launch<1>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            case 2: rc = launch<2>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            default: rc = launch<3>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+        }
+        if (rc) return rc;
+        first = false;
+        if (nslots == 0) break;
+    }
+    return OFX_OK;
+}
