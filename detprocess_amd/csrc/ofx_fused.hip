@@ -29,26 +29,30 @@ namespace {
 
 constexpr int FN = 32768;          // samples
 constexpr int FM = 16384;          // packed complex points
-constexpr int FT = 512;            // threads
-constexpr int LD1 = 513;           // D1 row stride (float2)
-constexpr int LD2 = 17;            // D2 row stride (float2)
-constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 float2 >= 32*513, >= 16384
-constexpr int NLOW_MAX = 1024;
+constexpr int FT = 512;            // threads per workgroup
+constexpr int WG_PER_CU = 2;       // two workgroups share a CU: one computes while the
+                                   // other waits on LDS / barriers / HBM
+constexpr int LD1 = 513;           // D1 row stride (floats)
+constexpr int LD2 = 17;            // D2 row stride (floats)
+constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 floats >= 32*513, >= 16384
+constexpr int NLOW_MAX = 512;
 constexpr int NWAVE = FT / OFX_WAVE;
 
+// LDS: real and imaginary parts go through the exchange buffer separately, so a
+// workgroup needs 68 KiB (not 136) and two of them fit the CU's 160 KiB.
 struct FusedLds {
-    float2 xbuf[XBUF_ELEMS];       // 139,264 B   exchange buffer / lag dump
-    float2 t2[512];                //   4,096 B   w_512^{n3 k2}, index k2*16+n3
-    float2 xlow[NLOW_MAX + 8];     //   8,256 B   2*X_k for k < 1024 (lowchi2)
+    float xb[XBUF_ELEMS];          // 69,632 B   exchange buffer / half lag dump
+    float2 t2[512];                //  4,096 B   w_512^{n3 k2}, index k2*16+n3
+    float2 xlow[NLOW_MAX + 8];     //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
-    unsigned long long bal[NWAVE];
     OfxCand cand[NWAVE];
+    OfxCand sres[OFX_MAX_SEARCHES];
     float bcast[8];
 };
-static_assert(sizeof(FusedLds) <= 160 * 1024, "LDS budget");
+static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
 
 struct FusedTabs {
-    const float2* t1;     // [32][512]  w_M^{n' k1}
+    const float2* t1;     // [16][512][2]  (w_M^{n' 2kq}, w_M^{n' (2kq+1)}) as float4 rows
     const float2* t2;     // [32][16]   w_512^{n3 k2}
     const float4* midA;   // [16][512]  (t_k.x, t_k.y, W_k.x/2, W_k.y/2)
     const float4* midB;   // [16][512]  (conj(W_p).x/2, conj(W_p).y/2, g_k', g_p')
@@ -92,122 +96,178 @@ __device__ __forceinline__ float2 sel(bool c, float2 a, float2 b) {
 // Middle step over the 32 values of a thread.  A = d[0..15] (block k_low = v),
 // B = d[16..31] (partner block).  Generic thread: slot j pairs (A[j], B[15-j]).
 // Thread 0 (blocks 0 and 512, both self-paired) is brought to the same slot
-// shape by a register permutation, applied only in the wave that holds it.
-template <bool WAVE0>
-__device__ __forceinline__ float middle(float2 (&d)[32], const FusedTabs& tabs, int v,
-                                        FusedLds& L) {
-    float2 a8 = d[8];
-    if constexpr (WAVE0) {
-        const bool z = (v == 0);
-        // genA = [A0[0..7], B0[0..7]] ; genB = [B0[8..15], A0[9..15], A0[0]]
-        float2 n[32];
+// shape by a register permutation (perm_in / perm_out), applied only in the
+// wave that holds it.
+__device__ __forceinline__ void perm_in(float2 (&d)[32], int v) {
+    const bool z = (v == 0);
+    // genA = [A0[0..7], B0[0..7]] ; genB = [B0[8..15], A0[9..15], A0[0]]
+    float2 n[32];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) n[j] = d[j];
+    for (int j = 0; j < 8; ++j) n[j] = d[j];
 #pragma unroll
-        for (int j = 8; j < 16; ++j) n[j] = sel(z, d[16 + j - 8], d[j]);
+    for (int j = 8; j < 16; ++j) n[j] = sel(z, d[16 + j - 8], d[j]);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[16 + 8 + i], d[16 + i]);
+    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[16 + 8 + i], d[16 + i]);
 #pragma unroll
-        for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[(i + 1) % 16], d[16 + i]);
+    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[(i + 1) % 16], d[16 + i]);
 #pragma unroll
-        for (int j = 0; j < 32; ++j) d[j] = n[j];
-    }
+    for (int j = 0; j < 32; ++j) d[j] = n[j];
+}
+
+__device__ __forceinline__ float perm_out(float2 (&d)[32], int v, float2 a8,
+                                          const FusedTabs& tabs, float chi) {
+    const bool z = (v == 0);
+    // self-paired bin k = M/2 (thread 0, A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
+    const float2 zq = cmulc(a8, tabs.wq);
+    if (z) chi = fmaf(2.0f * tabs.gq, fmaf(a8.x, a8.x, a8.y * a8.y), chi);
+    float2 n[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) n[j] = d[j];
+    // A0[8] special, A0[9..15] = genB[8..14], A0[0] = genA[0] (genB[15] discarded)
+    n[8] = sel(z, make_float2(2.0f * zq.x, 2.0f * zq.y), d[8]);
+#pragma unroll
+    for (int j = 9; j < 16; ++j) n[j] = sel(z, d[16 + j - 1], d[j]);
+    // B0[0..7] = genA[8..15] ; B0[8..15] = genB[0..7]
+#pragma unroll
+    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[8 + i], d[16 + i]);
+#pragma unroll
+    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[16 + i - 8], d[16 + i]);
+#pragma unroll
+    for (int j = 0; j < 32; ++j) d[j] = n[j];
+    return chi;
+}
+
+// 16 pair slots; table rows are software-pipelined two slots ahead so that at
+// most three rows (24 VGPRs) are in flight.
+__device__ __forceinline__ float middle_slots(float2 (&d)[32], const FusedTabs& tabs, int v,
+                                              FusedLds& L) {
+    float4 ta[3], tb[3];
+    ta[0] = tabs.midA[0 * FT + v];
+    tb[0] = tabs.midB[0 * FT + v];
+    ta[1] = tabs.midA[1 * FT + v];
+    tb[1] = tabs.midB[1 * FT + v];
     float chi = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float4 ta = tabs.midA[j * FT + v];
-        const float4 tb = tabs.midB[j * FT + v];
-        float2 xk2, xp2;
-        chi += mid_slot(d[j], d[16 + 15 - j], ta, tb, xk2, xp2);
-        if (j == 0) L.xlow[v] = xk2;                         // k = v (DC for v = 0)
-        if constexpr (WAVE0) {
-            if (j == 8 && v == 0) L.xlow[512] = xk2;          // thread 0: k = 512
-            if (j == 15 && v != 0) L.xlow[1024 - v] = make_float2(xp2.x, -xp2.y);
-        } else {
-            if (j == 15) L.xlow[1024 - v] = make_float2(xp2.x, -xp2.y);
+        if (j + 2 < 16) {
+            ta[(j + 2) % 3] = tabs.midA[(j + 2) * FT + v];
+            tb[(j + 2) % 3] = tabs.midB[(j + 2) * FT + v];
         }
-    }
-    if constexpr (WAVE0) {
-        const bool z = (v == 0);
-        // self-paired bin k = M/2 (thread 0, A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
-        const float2 zq = cmulc(a8, tabs.wq);
-        if (z) chi = fmaf(2.0f * tabs.gq, fmaf(a8.x, a8.x, a8.y * a8.y), chi);
-        // undo the permutation
-        float2 n[32];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) n[j] = d[j];
-        // A0[8] special, A0[9..15] = genB[8..14], A0[0] = genA[0] (genB[15] discarded)
-        n[8] = sel(z, make_float2(2.0f * zq.x, 2.0f * zq.y), d[8]);
-#pragma unroll
-        for (int j = 9; j < 16; ++j) n[j] = sel(z, d[16 + j - 1], d[j]);
-        // B0[0..7] = genA[8..15] ; B0[8..15] = genB[0..7]
-#pragma unroll
-        for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[8 + i], d[16 + i]);
-#pragma unroll
-        for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[16 + i - 8], d[16 + i]);
-#pragma unroll
-        for (int j = 0; j < 32; ++j) d[j] = n[j];
+        __builtin_amdgcn_sched_barrier(0);
+        float2 xk2, xp2;
+        chi += mid_slot(d[j], d[16 + 15 - j], ta[j % 3], tb[j % 3], xk2, xp2);
+        if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
+        __builtin_amdgcn_sched_barrier(0);
     }
     return chi;
+}
+
+// Inter-stage twiddles w_M^{n' k1} (F1: multiply, I1: multiply by the conjugate).
+// t1q[kq][tid] packs (w^{2kq}, w^{2kq+1}); rows are streamed in groups of four
+// (8 twiddles, 16 VGPRs), the next group in flight while one is applied.
+struct T1Group {
+    float4 q[4];
+};
+__device__ __forceinline__ T1Group t1_load(const float4* t1q, int tid, int g) {
+    T1Group r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r.q[c] = t1q[(4 * g + c) * FT + tid];
+    return r;
+}
+template <bool CONJ>
+__device__ __forceinline__ void t1_apply(float2 (&d)[32], const float4* t1q, int tid,
+                                         T1Group cur) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        T1Group nxt;
+        if (g < 3) nxt = t1_load(t1q, tid, g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k1 = 8 * g + 2 * c;
+            const float2 w0 = make_float2(cur.q[c].x, cur.q[c].y);
+            const float2 w1 = make_float2(cur.q[c].z, cur.q[c].w);
+            if (k1 != 0) d[k1] = CONJ ? cmulc(d[k1], w0) : cmul(d[k1], w0);
+            d[k1 + 1] = CONJ ? cmulc(d[k1 + 1], w1) : cmul(d[k1 + 1], w1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < 3) cur = nxt;
+    }
+}
+
+// LDS exchange of 32 complex values per thread, real parts then imaginary parts.
+template <class WI, class RI>
+__device__ __forceinline__ void exchange(float2 (&d)[32], float* xb, WI widx, RI ridx) {
+    __syncthreads();                       // earlier readers of xb are done
+#pragma unroll
+    for (int j = 0; j < 32; ++j) xb[widx(j)] = d[j].x;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) d[j].x = xb[ridx(j)];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) xb[widx(j)] = d[j].y;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; ++j) d[j].y = xb[ridx(j)];
 }
 
 // ------------------------------------------------------------------ the kernel
 // FEAT bit 0: plan has searches that are not full-range (scan the LDS lag dump)
 // FEAT bit 1: plan has time-domain windows
+// FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
 template <int FEAT>
-__global__ __launch_bounds__(FT) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
-                                              const float* __restrict__ traces,
-                                              const uint8_t* __restrict__ valid,
-                                              long long n_traces, float* __restrict__ out) {
+__global__ __launch_bounds__(FT, 4) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
+                                                 const float* __restrict__ traces,
+                                                 const uint8_t* __restrict__ valid,
+                                                 long long n_traces, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     FusedLds& L = *reinterpret_cast<FusedLds*>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int n3u = tid >> 5, k1u = tid & 31;       // F2 / I2 role
     const int kB = partner_block(tid);              // F3 / I3 role
+    const int pre = pd.pre;
+    const float4* t1q = reinterpret_cast<const float4*>(tabs.t1);
 
     for (int i = tid; i < 512; i += FT) L.t2[i] = tabs.t2[i];
-    __syncthreads();
 
     const size_t ev_stride = (size_t)pd.n_channels * FN;
     float2 d[32];
-    float2 pf[32];
-    long long b = blockIdx.x;
 
-    auto load_trace = [&](long long bb, float2 (&dst)[32]) {
-        const float* e = traces + (size_t)bb * ev_stride;
-        if (pd.n_terms == 1 && pd.weight[0] == 1.0f) {
-            const float2* z = reinterpret_cast<const float2*>(e + (size_t)pd.chan[0] * FN);
-#pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) dst[n1] = z[512 * n1 + tid];
-        } else {
-#pragma unroll
-            for (int n1 = 0; n1 < 32; ++n1) dst[n1] = make_float2(0.f, 0.f);
-            for (int j = 0; j < pd.n_terms; ++j) {
-                const float2* z = reinterpret_cast<const float2*>(e + (size_t)pd.chan[j] * FN);
-                const float wgt = pd.weight[j];
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) {
-                    const float2 s = z[512 * n1 + tid];
-                    dst[n1].x = fmaf(wgt, s.x, dst[n1].x);
-                    dst[n1].y = fmaf(wgt, s.y, dst[n1].y);
-                }
-            }
-        }
-    };
+    auto e1w = [&](int k1) { return k1 * LD1 + tid; };
+    auto e1r = [&](int n2) { return k1u * LD1 + 16 * n2 + n3u; };
+    auto e2w = [&](int k2) { return (k1u + 32 * k2) * LD2 + n3u; };
+    auto e2r = [&](int j) { return (j < 16 ? tid : kB) * LD2 + (j & 15); };
 
-    if (b < n_traces) load_trace(b, pf);
-
-    for (; b < n_traces; b += gridDim.x) {
-#pragma unroll
-        for (int j = 0; j < 32; ++j) d[j] = pf[j];
-        const long long bn = b + gridDim.x;
+    for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
         float* row = out + (size_t)b * pd.row;
-        const bool ok = !(valid && !valid[b]);
-        if (!ok) {
-            if (bn < n_traces) load_trace(bn, pf);
+        if (valid && !valid[b]) {
             for (int j = tid; j < pd.row; j += FT) row[j] = OFX_SENTINEL;
             continue;
+        }
+        // ------------------------------------------------------------- load
+        {
+            const float* e = traces + (size_t)b * ev_stride;
+            if constexpr (FEAT & 4) {
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) d[n1] = make_float2(0.f, 0.f);
+                for (int j = 0; j < pd.n_terms; ++j) {
+                    const float2* z =
+                        reinterpret_cast<const float2*>(e + (size_t)pd.chan[j] * FN);
+                    const float wgt = pd.weight[j];
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) {
+                        const float2 s = z[512 * n1 + tid];
+                        d[n1].x = fmaf(wgt, s.x, d[n1].x);
+                        d[n1].y = fmaf(wgt, s.y, d[n1].y);
+                    }
+                }
+            } else {
+                const float2* z = reinterpret_cast<const float2*>(e);
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) d[n1] = z[512 * n1 + tid];
+            }
         }
 
         // ------------------------------------------------ time-domain windows
@@ -252,73 +312,40 @@ __global__ __launch_bounds__(FT) void k_fused(OfxPlanDev pd, OfxSlotDev sd, Fuse
                 }
             }
         }
-        if (sd.n_search == 0) {
-            if (bn < n_traces) load_trace(bn, pf);
-            continue;
-        }
+        if (sd.n_search == 0) continue;
 
         // ---------------------------------------------------------------- F1
-        dft<32, -1>(d);
         {
-            float2 tw[32];
-#pragma unroll
-            for (int k1 = 1; k1 < 32; ++k1) tw[k1] = tabs.t1[k1 * 512 + tid];
-            // prefetch the next trace behind the twiddle loads (vmcnt is in-order)
-            if (bn < n_traces) load_trace(bn, pf);
-#pragma unroll
-            for (int k1 = 1; k1 < 32; ++k1) d[k1] = cmul(d[k1], tw[k1]);
+            const T1Group g0 = t1_load(t1q, tid, 0);
+            dft<32, -1>(d);
+            t1_apply<false>(d, t1q, tid, g0);
         }
-        __syncthreads();                       // previous trace's LDS readers are done
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) L.xbuf[k1 * LD1 + tid] = d[k1];
-        __syncthreads();
+        exchange(d, L.xb, e1w, e1r);
         // ---------------------------------------------------------------- F2
-#pragma unroll
-        for (int n2 = 0; n2 < 32; ++n2) d[n2] = L.xbuf[k1u * LD1 + 16 * n2 + n3u];
         dft<32, -1>(d);
 #pragma unroll
         for (int k2 = 1; k2 < 32; ++k2) d[k2] = cmul(d[k2], L.t2[k2 * 16 + n3u]);
-        __syncthreads();
-#pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) L.xbuf[(k1u + 32 * k2) * LD2 + n3u] = d[k2];
-        __syncthreads();
-        // ---------------------------------------------------------------- F3
-#pragma unroll
-        for (int n3 = 0; n3 < 16; ++n3) {
-            d[n3] = L.xbuf[tid * LD2 + n3];
-            d[16 + n3] = L.xbuf[kB * LD2 + n3];
-        }
+        exchange(d, L.xb, e2w, e2r);
+        // ------------------------------------------- F3, middle, I3 (registers)
         dft<16, -1, 32, 0>(d);
         dft<16, -1, 32, 16>(d);
-        // ------------------------------------------------------------ middle
-        float chi0p;
-        if (wave == 0) chi0p = middle<true>(d, tabs, tid, L);
-        else chi0p = middle<false>(d, tabs, tid, L);
-        // ---------------------------------------------------------------- I3
+        const float2 a8 = d[8];
+        if (wave == 0) perm_in(d, tid);
+        float chi0p = middle_slots(d, tabs, tid, L);
+        if (wave == 0) chi0p = perm_out(d, tid, a8, tabs, chi0p);
         dft<16, +1, 32, 0>(d);
         dft<16, +1, 32, 16>(d);
-        __syncthreads();
-#pragma unroll
-        for (int n3 = 0; n3 < 16; ++n3) {
-            L.xbuf[tid * LD2 + n3] = d[n3];
-            L.xbuf[kB * LD2 + n3] = d[16 + n3];
-        }
-        __syncthreads();
+        exchange(d, L.xb, e2r, e2w);
         // ---------------------------------------------------------------- I2
-#pragma unroll
-        for (int k2 = 0; k2 < 32; ++k2) d[k2] = L.xbuf[(k1u + 32 * k2) * LD2 + n3u];
 #pragma unroll
         for (int k2 = 1; k2 < 32; ++k2) d[k2] = cmulc(d[k2], L.t2[k2 * 16 + n3u]);
         dft<32, +1>(d);
-        __syncthreads();
-#pragma unroll
-        for (int n2 = 0; n2 < 32; ++n2) L.xbuf[k1u * LD1 + 16 * n2 + n3u] = d[n2];
-        __syncthreads();
-        // ---------------------------------------------------------------- I1
-#pragma unroll
-        for (int k1 = 0; k1 < 32; ++k1) d[k1] = L.xbuf[k1 * LD1 + tid];
-#pragma unroll
-        for (int k1 = 1; k1 < 32; ++k1) d[k1] = cmulc(d[k1], tabs.t1[k1 * 512 + tid]);
+        {
+            const T1Group g0 = t1_load(t1q, tid, 0);
+            exchange(d, L.xb, e1r, e1w);
+            // ------------------------------------------------------------ I1
+            t1_apply<true>(d, t1q, tid, g0);
+        }
         dft<32, +1>(d);
         // d[n1] = (A(1024 n1 + 2 tid), A(1024 n1 + 2 tid + 1))
 
@@ -327,76 +354,71 @@ __global__ __launch_bounds__(FT) void k_fused(OfxPlanDev pd, OfxSlotDev sd, Fuse
 #pragma unroll
         for (int n1 = 0; n1 < 32; ++n1)
             mloc = fmaxf(mloc, fmaxf(d[n1].x * d[n1].x, d[n1].y * d[n1].y));
-        const float wmax = ofx_wave_max(mloc);
-        const float wchi = ofx_wave_sum(chi0p);
-        __syncthreads();                       // every E4 read is done -> dump lags
-#pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1) L.xbuf[512 * n1 + tid] = d[n1];
-        if (lane == 0) {
-            L.red[0][wave] = wmax;
-            L.red[1][wave] = wchi;
+        {
+            const float wmax = ofx_wave_max(mloc);
+            const float wchi = ofx_wave_sum(chi0p);
+            __syncthreads();
+            if (lane == 0) {
+                L.red[0][wave] = wmax;
+                L.red[1][wave] = wchi;
+            }
+            if (tid == 0) L.bcast[0] = d[0].x;          // A(lag 0) for nodelay
+            __syncthreads();
         }
-        __syncthreads();
-        const float* alag = reinterpret_cast<const float*>(L.xbuf);   // A(n), natural lag order
         float Mstar = L.red[0][0], chi0 = L.red[1][0];
 #pragma unroll
         for (int q = 1; q < NWAVE; ++q) {
             Mstar = fmaxf(Mstar, L.red[0][q]);
             chi0 += L.red[1][q];
         }
-        // threads whose local maximum equals the global one
-        {
-            const unsigned long long bm = __ballot(mloc == Mstar);
-            if (lane == 0) L.bal[wave] = bm;
-        }
-        __syncthreads();
+        const float a_lag0 = L.bcast[0];
 
-        const int pre = pd.pre;
+        // full-range delay fit: the thread(s) holding the maximum resolve the
+        // smallest rolled index among their lags with A^2 == max
+        OfxCand fullbest = ofx_cand_none();
+        bool any_full = false;
         for (int q = 0; q < sd.n_search; ++q) {
-            const OfxSearchDev sq = sd.search[q];
-            OfxCand best;
-            const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
-                              sq.hi == FN;
-            if (sq.kind == OFX_SEARCH_NODELAY) {
-                best.amp = alag[0];
-                best.idx = pre;
-                best.key = best.amp * best.amp;
-            } else if (full) {
-                // wave 0 resolves the smallest rolled index among lags with A^2 == Mstar
-                if (wave == 0) {
-                    int bi = 0x7fffffff;
-                    for (int w = 0; w < NWAVE; ++w) {
-                        unsigned long long bm = L.bal[w];
-                        while (bm) {
-                            const int bit = __ffsll((long long)bm) - 1;
-                            bm &= bm - 1;
-                            const int ts = w * 64 + bit;
-                            const int n = 1024 * (lane >> 1) + 2 * ts + (lane & 1);
-                            const float a = alag[n];
-                            const int ri = (n + pre) & (FN - 1);
-                            int c = (a * a == Mstar) ? ri : 0x7fffffff;
+            const OfxSearchDev& sq = sd.search[q];
+            any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
+                        sq.hi == FN;
+        }
+        if (any_full) {
+            if (mloc == Mstar) {
+                const int base = 2 * tid + pre;
 #pragma unroll
-                            for (int off = 32; off > 0; off >>= 1)
-                                c = min(c, __shfl_xor(c, off, 64));
-                            bi = min(bi, c);
-                        }
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    const int i0 = (base + 1024 * n1) & (FN - 1);
+                    const int i1 = (base + 1024 * n1 + 1) & (FN - 1);
+                    if (d[n1].x * d[n1].x == Mstar && i0 < fullbest.idx) {
+                        fullbest.idx = i0; fullbest.amp = d[n1].x; fullbest.key = Mstar;
                     }
-                    if (lane == 0) {
-                        L.bcast[0] = __int_as_float(bi);
-                        L.bcast[1] = alag[(bi - pre) & (FN - 1)];
+                    if (d[n1].y * d[n1].y == Mstar && i1 < fullbest.idx) {
+                        fullbest.idx = i1; fullbest.amp = d[n1].y; fullbest.key = Mstar;
                     }
                 }
+            }
+            fullbest = ofx_cand_block_reduce(fullbest, L.cand);
+        }
+
+        // windowed / outside-window fits scan the lag dump, even lags then odd
+        if constexpr (FEAT & 1) {
+            if (tid < OFX_MAX_SEARCHES) L.sres[tid] = ofx_cand_none();
+            for (int e = 0; e < 2; ++e) {
                 __syncthreads();
-                best.idx = __float_as_int(L.bcast[0]);
-                best.amp = L.bcast[1];
-                best.key = Mstar;
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1)
+                    L.xb[512 * n1 + tid] = e ? d[n1].y : d[n1].x;   // A(2m+e) at m
                 __syncthreads();
-            } else {
-                best = ofx_cand_none();
-                if constexpr (FEAT & 1) {
+                for (int q = 0; q < sd.n_search; ++q) {
+                    const OfxSearchDev& sq = sd.search[q];
+                    const bool full = !sq.outside && sq.lo == 0 && sq.hi == FN;
+                    if (sq.kind != OFX_SEARCH_DELAY || full) continue;
+                    OfxCand c = ofx_cand_none();
                     auto scan = [&](int i0, int i1) {
-                        for (int i = i0 + tid; i < i1; i += FT)
-                            ofx_cand_take(best, alag[(i - pre) & (FN - 1)], i);
+                        for (int i = i0 + tid; i < i1; i += FT) {
+                            const int n = (i - pre) & (FN - 1);
+                            if ((n & 1) == e) ofx_cand_take(c, L.xb[n >> 1], i);
+                        }
                     };
                     if (sq.outside) {
                         scan(0, sq.lo);
@@ -404,8 +426,27 @@ __global__ __launch_bounds__(FT) void k_fused(OfxPlanDev pd, OfxSlotDev sd, Fuse
                     } else {
                         scan(sq.lo, sq.hi);
                     }
-                    best = ofx_cand_block_reduce(best, L.cand);
+                    c = ofx_cand_block_reduce(c, L.cand);
+                    if (tid == 0 && ofx_cand_better(c.key, c.idx, L.sres[q])) L.sres[q] = c;
                 }
+            }
+            __syncthreads();
+        }
+
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev sq = sd.search[q];
+            OfxCand best;
+            const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
+                              sq.hi == FN;
+            if (sq.kind == OFX_SEARCH_NODELAY) {
+                best.amp = a_lag0;
+                best.idx = pre;
+                best.key = a_lag0 * a_lag0;
+            } else if (full) {
+                best = fullbest;
+            } else {
+                if constexpr (FEAT & 1) best = L.sres[q];
+                else best = ofx_cand_none();
             }
             // low-frequency chi2 at (amp, t0)
             const int dl = best.idx - pre;
@@ -448,7 +489,9 @@ static int fused_tables(ofx_plan* p) {
         for (int n = 0; n < 512; ++n) {
             const long long e = ((long long)k1 * n) % FM;
             const double a = -PI2 * (double)e / FM;
-            t1[k1 * 512 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+            // packed as float4 rows: t1q[k1/2][n] = (w^{k1 even}, w^{k1 odd})
+            t1[((k1 >> 1) * 512 + n) * 2 + (k1 & 1)] =
+                make_float2((float)std::cos(a), (float)std::sin(a));
         }
     for (int k2 = 0; k2 < 32; ++k2)
         for (int n3 = 0; n3 < 16; ++n3) {
@@ -522,7 +565,7 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
                                     (int)sizeof(FusedLds)));
         attr_set = true;
     }
-    long long grid = p->cu_count;
+    long long grid = (long long)p->cu_count * WG_PER_CU;
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
@@ -582,12 +625,17 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             }
         }
         if (pdl.n_tdwin > 0) feat |= 2;
+        if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
         int rc;
         switch (feat) {
             case 0: rc = launch<0>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
             case 1: rc = launch<1>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
             case 2: rc = launch<2>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            default: rc = launch<3>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            case 3: rc = launch<3>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            case 4: rc = launch<4>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            case 5: rc = launch<5>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            case 6: rc = launch<6>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            default: rc = launch<7>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
         }
         if (rc) return rc;
         first = false;
