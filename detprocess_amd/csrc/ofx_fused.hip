@@ -30,8 +30,11 @@ namespace {
 constexpr int FN = 32768;          // samples
 constexpr int FM = 16384;          // packed complex points
 constexpr int FT = 512;            // threads per workgroup
-constexpr int WG_PER_CU = 2;       // two workgroups share a CU: one computes while the
-                                   // other waits on LDS / barriers / HBM
+#ifndef OFX_WG_PER_CU
+#define OFX_WG_PER_CU 1
+#endif
+constexpr int WG_PER_CU = OFX_WG_PER_CU;   // workgroups resident per CU (2: one computes
+                                           // while the other waits on LDS / barriers / HBM)
 constexpr int LD1 = 513;           // D1 row stride (floats)
 constexpr int LD2 = 17;            // D2 row stride (floats)
 constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 floats >= 32*513, >= 16384
@@ -61,6 +64,23 @@ struct FusedTabs {
 };
 
 __device__ __forceinline__ int partner_block(int v) { return v == 0 ? 512 : 1024 - v; }
+
+// Buffer loads: descriptor in SGPRs, one 32-bit VGPR byte offset per lane, the
+// row offset in an SGPR -- no per-row 64-bit VGPR addresses to keep alive.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                       __uint_as_float(v.w));
+}
+__device__ __forceinline__ float2 buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
 
 // ---- the pairwise middle step on one (Z_k, Z_p) slot -------------------------
 // in : zk = Z_k, zp = Z_p (p = M - k)      out: zk = Z'_k, zp = Z'_p
@@ -139,25 +159,31 @@ __device__ __forceinline__ float perm_out(float2 (&d)[32], int v, float2 a8,
 
 // 16 pair slots; table rows are software-pipelined two slots ahead so that at
 // most three rows (24 VGPRs) are in flight.
-__device__ __forceinline__ float middle_slots(float2 (&d)[32], const FusedTabs& tabs, int v,
-                                              FusedLds& L) {
+__device__ __forceinline__ float middle_slots(float2 (&d)[32], __amdgpu_buffer_rsrc_t rmid,
+                                              int v, FusedLds& L) {
+    // rmid covers [midA: 16 rows][midB: 16 rows], 8 KiB per row
     float4 ta[3], tb[3];
-    ta[0] = tabs.midA[0 * FT + v];
-    tb[0] = tabs.midB[0 * FT + v];
-    ta[1] = tabs.midA[1 * FT + v];
-    tb[1] = tabs.midB[1 * FT + v];
+    const int vo = v * 16;
+    ta[0] = buf_ld4(rmid, vo, 0 * 8192);
+    tb[0] = buf_ld4(rmid, vo, (16 + 0) * 8192);
+    ta[1] = buf_ld4(rmid, vo, 1 * 8192);
+    tb[1] = buf_ld4(rmid, vo, (16 + 1) * 8192);
     float chi = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         if (j + 2 < 16) {
-            ta[(j + 2) % 3] = tabs.midA[(j + 2) * FT + v];
-            tb[(j + 2) % 3] = tabs.midB[(j + 2) * FT + v];
+            ta[(j + 2) % 3] = buf_ld4(rmid, vo, (j + 2) * 8192);
+            tb[(j + 2) % 3] = buf_ld4(rmid, vo, (16 + j + 2) * 8192);
         }
+#ifndef NO_SB
         __builtin_amdgcn_sched_barrier(0);
+#endif
         float2 xk2, xp2;
         chi += mid_slot(d[j], d[16 + 15 - j], ta[j % 3], tb[j % 3], xk2, xp2);
         if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
+#ifndef NO_SB
         __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     return chi;
 }
@@ -168,14 +194,14 @@ __device__ __forceinline__ float middle_slots(float2 (&d)[32], const FusedTabs& 
 struct T1Group {
     float4 q[4];
 };
-__device__ __forceinline__ T1Group t1_load(const float4* t1q, int tid, int g) {
+__device__ __forceinline__ T1Group t1_load(__amdgpu_buffer_rsrc_t t1q, int tid, int g) {
     T1Group r;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r.q[c] = t1q[(4 * g + c) * FT + tid];
+    for (int c = 0; c < 4; ++c) r.q[c] = buf_ld4(t1q, tid * 16, (4 * g + c) * 8192);
     return r;
 }
 template <bool CONJ>
-__device__ __forceinline__ void t1_apply(float2 (&d)[32], const float4* t1q, int tid,
+__device__ __forceinline__ void t1_apply(float2 (&d)[32], __amdgpu_buffer_rsrc_t t1q, int tid,
                                          T1Group cur) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -217,7 +243,7 @@ __device__ __forceinline__ void exchange(float2 (&d)[32], float* xb, WI widx, RI
 // FEAT bit 1: plan has time-domain windows
 // FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
 template <int FEAT>
-__global__ __launch_bounds__(FT, 4) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
+__global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
                                                  const float* __restrict__ traces,
                                                  const uint8_t* __restrict__ valid,
                                                  long long n_traces, float* __restrict__ out) {
@@ -228,7 +254,8 @@ __global__ __launch_bounds__(FT, 4) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
     const int n3u = tid >> 5, k1u = tid & 31;       // F2 / I2 role
     const int kB = partner_block(tid);              // F3 / I3 role
     const int pre = pd.pre;
-    const float4* t1q = reinterpret_cast<const float4*>(tabs.t1);
+    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 32 * 512 * 8);
+    const __amdgpu_buffer_rsrc_t rmid = make_rsrc(tabs.midA, 2 * 16 * 512 * 16);
 
     for (int i = tid; i < 512; i += FT) L.t2[i] = tabs.t2[i];
 
@@ -256,17 +283,18 @@ __global__ __launch_bounds__(FT, 4) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
                     const float2* z =
                         reinterpret_cast<const float2*>(e + (size_t)pd.chan[j] * FN);
                     const float wgt = pd.weight[j];
+                    const __amdgpu_buffer_rsrc_t rz = make_rsrc(z, FN * 4);
 #pragma unroll
                     for (int n1 = 0; n1 < 32; ++n1) {
-                        const float2 s = z[512 * n1 + tid];
+                        const float2 s = buf_ld2(rz, tid * 8, n1 * 4096);
                         d[n1].x = fmaf(wgt, s.x, d[n1].x);
                         d[n1].y = fmaf(wgt, s.y, d[n1].y);
                     }
                 }
             } else {
-                const float2* z = reinterpret_cast<const float2*>(e);
+                const __amdgpu_buffer_rsrc_t rz = make_rsrc(e, FN * 4);
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) d[n1] = z[512 * n1 + tid];
+                for (int n1 = 0; n1 < 32; ++n1) d[n1] = buf_ld2(rz, tid * 8, n1 * 4096);
             }
         }
 
@@ -330,9 +358,13 @@ __global__ __launch_bounds__(FT, 4) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
         dft<16, -1, 32, 0>(d);
         dft<16, -1, 32, 16>(d);
         const float2 a8 = d[8];
+#ifndef NO_PERM
         if (wave == 0) perm_in(d, tid);
-        float chi0p = middle_slots(d, tabs, tid, L);
+#endif
+        float chi0p = middle_slots(d, rmid, tid, L);
+#ifndef NO_PERM
         if (wave == 0) chi0p = perm_out(d, tid, a8, tabs, chi0p);
+#endif
         dft<16, +1, 32, 0>(d);
         dft<16, +1, 32, 16>(d);
         exchange(d, L.xb, e2r, e2w);
@@ -384,7 +416,8 @@ __global__ __launch_bounds__(FT, 4) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
         }
         if (any_full) {
             if (mloc == Mstar) {
-                const int base = 2 * tid + pre;
+                int base = 2 * tid + pre;
+                asm volatile("" : "+v"(base));   // keep the 64 rolled indices out of LICM
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
                     const int i0 = (base + 1024 * n1) & (FN - 1);
