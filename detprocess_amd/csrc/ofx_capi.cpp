@@ -364,7 +364,7 @@ static int ensure(float** buf, size_t* have, size_t want) {
 extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* valid,
                            long long n, int traces_mem, float* out, int out_mem,
                            void* stream) {
-    if (!p || !traces || !out || n < 0) {
+    if (!p || n < 0 || (n > 0 && (!traces || !out))) {
         ofx_set_error("ofx_process: bad argument");
         return OFX_ERR_ARG;
     }

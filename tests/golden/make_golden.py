@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the fp64 oracle.
+
+The reference itself cannot be imported here (QETpy / vaex / pytesio absent --
+SURVEY.md section 8c), so these vectors pin "our fp64 restatement", not QETpy.
+Inputs are stored as float32 (exactly what the GPU engine consumes); expected
+values are the oracle's fp64 results on those float32 inputs.
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from detprocess_amd import synth          # noqa: E402
+from oracle import of1x1 as orc           # noqa: E402
+
+FS = 1.25e6
+
+
+def make(n_samples, n_traces, seed, pre=None, fname=None):
+    pre = n_samples // 2 if pre is None else pre
+    tmpl = synth.make_template(n_samples, pre, FS)
+    psd = synth.make_psd(n_samples, FS)
+    filt = orc.OFFilter(tmpl, psd, FS, pre)
+    traces, amps, delays = synth.make_traces(n_traces, tmpl, psd, FS, filt.ampres,
+                                             seed=seed, max_delay=n_samples // 8)
+    tr32 = traces.astype(np.float32)
+    x = tr32.astype(np.float64)
+    half = 500 * n_samples // 32768
+    win_us = half / FS * 1e6
+    out = {"template": tmpl, "psd": psd, "fs": FS, "pre": pre, "traces": tr32,
+           "true_amp": amps, "true_delay": delays, "win_us": win_us}
+    for mode, kw in (("nodelay", {}), ("unconstrained", {}),
+                     ("constrained", dict(window_min_from_trig_usec=-win_us,
+                                          window_max_from_trig_usec=win_us)),
+                     ("outside", dict(window_min_from_trig_usec=-win_us,
+                                      window_max_from_trig_usec=win_us,
+                                      lgc_outside_window=True))):
+        m = "constrained" if mode == "outside" else mode
+        r = orc.process_events(filt, x, m, **kw)
+        for k, v in r.items():
+            out[f"{mode}_{k}"] = v
+    lo, hi = orc.search_range(filt, -win_us, win_us)
+    out["window_lo"], out["window_hi"] = lo, hi
+    wins = [(0, n_samples - 1), (n_samples // 16, pre), (pre - 3, pre + 200), (7, 8)]
+    out["td_windows"] = np.array(wins)
+    for i, (a, b) in enumerate(wins):
+        out[f"td{i}_baseline"] = orc.baseline(x, a, b)
+        out[f"td{i}_integral"] = orc.integral(x, FS, a, b)
+        out[f"td{i}_maximum"] = orc.maximum(x, a, b)
+        out[f"td{i}_minimum"] = orc.minimum(x, a, b)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written:", n_traces, "x", n_samples)
+
+
+if __name__ == "__main__":
+    make(4096, 32, seed=41, fname="golden_n4096.npz")
+    make(4096, 8, seed=42, pre=1000, fname="golden_n4096_pre1000.npz")
+    make(32768, 6, seed=43, fname="golden_n32768.npz")
+    make(25000, 4, seed=44, pre=12500, fname="golden_n25000.npz")
