@@ -2,5 +2,10 @@
 
 from .engine import OFPlan, synth_traces          # noqa: F401
 from .filters import FilterTables, build_filter   # noqa: F401
+from .algorithms import FeatureExtractors         # noqa: F401
+from .config import YamlConfig                    # noqa: F401
+from .filterdata import FilterData                # noqa: F401
+from .ofbase import OFBase, search_range          # noqa: F401
+from .process import FeatureProcessing            # noqa: F401
 
 __version__ = "0.1.0"

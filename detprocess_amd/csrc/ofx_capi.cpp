@@ -84,9 +84,9 @@ void ofx_fill_slot_dev(const ofx_plan* p, int slot, OfxSlotDev* d) {
 
 extern "C" int ofx_plan_create(ofx_plan** out, int n_samples, int n_pretrigger,
                                double fs, int max_batch, int device, int engine) {
-    if (!out || n_samples < 8 || (n_samples & 1) || n_pretrigger < 0 ||
+    if (!out || n_samples < 8 || n_pretrigger < 0 ||
         n_pretrigger >= n_samples || !(fs > 0) || max_batch < 1) {
-        ofx_set_error("ofx_plan_create: bad argument (n_samples=%d must be even >= 8, "
+        ofx_set_error("ofx_plan_create: bad argument (n_samples=%d must be >= 8, "
                       "0 <= n_pretrigger=%d < n_samples, fs=%g > 0, max_batch=%d >= 1)",
                       n_samples, n_pretrigger, fs, max_batch);
         return OFX_ERR_ARG;
@@ -161,6 +161,11 @@ extern "C" int ofx_plan_set_filter(ofx_plan* p, int slot, const double* wf,
                                    double tres_sum) {
     if (!p || slot < 0 || slot >= OFX_MAX_SLOTS || !wf || !g || !s || !(norm > 0)) {
         ofx_set_error("ofx_plan_set_filter: bad argument (slot=%d, norm=%g)", slot, norm);
+        return OFX_ERR_ARG;
+    }
+    if (p->N & 1) {
+        ofx_set_error("ofx_plan_set_filter: odd trace lengths (%d) carry time-domain "
+                      "windows only", p->N);
         return OFX_ERR_ARG;
     }
     OFX_HIP(hipSetDevice(p->device));

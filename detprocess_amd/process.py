@@ -1,0 +1,249 @@
+"""FeatureProcessing: batched counterpart of the reference's per-event loop.
+
+The reference walks ``for event: for channel: for algorithm: extractor(...)``
+(``detprocess/process/features.py:533-851``).  Here the YAML feature section is
+compiled ONCE into one ``OFPlan`` per feature channel -- every of1x1 algorithm
+becomes a search on a filter slot, every trace algorithm a time-domain window
+-- and a whole batch of events ``[B, C, N]`` goes through the GPU in one call
+per feature channel.  What is reproduced from the reference, per (channel,
+algorithm): the kwargs (YAML keys minus ``run`` + ``fs``, ``nb_samples``,
+``nb_pretrigger_samples``; ``features.py:762-778``), the window indices
+(``:780-785``), the OF-plan key ``(nb_samples, nb_pretrigger, "<csd_tag>_<coupling>
+[_<peaks>]")`` (``:794-823``), ``base_algorithm`` dispatch (``:728-730``) and the
+output column names ``<feature>_<feature_channel>`` (``:842-846``).
+"""
+
+import numpy as np
+
+from . import _lib, utils
+from .config import YamlConfig
+from .engine import OFPlan
+from .filters import build_filter
+from .ofbase import search_range
+
+OF_ALGORITHMS = {
+    # base algorithm -> (search kind, quantities emitted)   algorithms.py:344-348 etc
+    "of1x1_nodelay": ("nodelay", ("amp", "chi2", "lowchi2")),
+    "of1x1_unconstrained": ("delay", ("amp", "t0", "chi2", "lowchi2")),
+    "of1x1_constrained": ("delay", ("amp", "t0", "chi2", "lowchi2", "chi2nopulse",
+                                    "ampres", "timeres")),
+}
+TD_ALGORITHMS = ("baseline", "integral", "maximum", "minimum")
+# algorithms whose base name contains one of these get an OFBase in the reference
+# (processing_data.py:93-97); the ones not implemented here raise explicitly
+OF_BASE_PREFIXES = ["of1x1", "of1x2x2", "of1x3x3", "ofnxm", "ofnxmx2", "psd_amp",
+                    "psd_peaks", "phase"]
+
+
+class _ChannelPlan:
+    def __init__(self):
+        self.plan = None
+        self.columns = []       # (column name, row offset)
+
+
+class FeatureProcessing:
+    def __init__(self, config, filter_data, available_channels, sample_rate,
+                 nb_samples=None, nb_pretrigger_samples=None, device=0, engine="auto",
+                 max_batch=8192, window_policy="qetpy"):
+        """config: YamlConfig, YAML path / text, or dict.  available_channels: the
+        channel names of axis 1 of the event array, in order."""
+        if isinstance(available_channels, str):
+            available_channels = [available_channels]
+        self._channels = list(available_channels)
+        self._fs = float(sample_rate)
+        if not isinstance(config, YamlConfig):
+            config = YamlConfig(config, self._channels, sample_rate=sample_rate)
+        self._config = config.get_config("feature")
+        self._filter_data = filter_data
+        self._device = device
+        self._engine = engine
+        self._max_batch = max_batch
+        self._policy = window_policy
+        self._nb_samples = nb_samples
+        self._nb_pretrigger = nb_pretrigger_samples
+        self._plans = None
+
+    # ----------------------------------------------------------------- compile
+    def _compile(self, n_samples):
+        plans = {}
+        weights_all = self._config.get("weights", {})
+        for channel, algorithms in self._config["channels"].items():
+            if not isinstance(algorithms, dict):
+                continue
+            feature_channel = algorithms.get("feature_channel", channel)
+            if "|" in channel:
+                raise ValueError(f'ERROR: multi-channel OF ("{channel}") is not supported '
+                                 f"by this engine (of1x1 family only)")
+            names, sep = utils.split_channel_name(channel, self._channels)
+            idx = [self._channels.index(c) for c in names]
+            w = np.ones(len(names))
+            if channel in weights_all:
+                for j, c in enumerate(names):
+                    key = f"weight_{c}"
+                    if key not in weights_all[channel]:
+                        raise ValueError(f"ERROR: Missing parameter weight {key} for "
+                                         f"channel {channel}!")     # processing_data.py:982-986
+                    w[j] = weights_all[channel][key]
+            if sep == "-":
+                if len(names) != 2:
+                    raise ValueError('ERROR: "-" needs exactly two channels')
+                w[1] = -w[1]
+            cp = _ChannelPlan()
+            slots = {}
+            td_windows = {}
+            pending = []
+            nb_pre_plan = None
+            for algorithm, params in algorithms.items():
+                if not isinstance(params, dict) or not params.get("run", False):
+                    continue
+                base = params.get("base_algorithm", algorithm)
+                nb = params.get("nb_samples") or self._nb_samples or n_samples
+                npre = params.get("nb_pretrigger_samples")
+                if npre is None:
+                    npre = self._nb_pretrigger if self._nb_pretrigger is not None else nb // 2
+                if nb != n_samples:
+                    raise ValueError(f"ERROR: Number of samples is not consistent between "
+                                     f"raw data (={n_samples}) and algorithm {algorithm} "
+                                     f"(={nb}) for channel {channel}!")
+                kwargs = {k: v for k, v in params.items() if k != "run"}
+                kwargs["fs"] = self._fs
+                kwargs.setdefault("nb_samples", nb)
+                kwargs.setdefault("nb_pretrigger_samples", npre)
+                kwargs["nb_samples"], kwargs["nb_pretrigger_samples"] = nb, npre
+                wmin, wmax = utils.get_window_indices(**kwargs)
+                if nb_pre_plan is None:
+                    nb_pre_plan = npre
+                if base in OF_ALGORITHMS:
+                    if npre != nb_pre_plan:
+                        raise ValueError("ERROR: one pretrigger length per feature channel")
+                    if "template_tag" not in params:
+                        raise ValueError(f'ERROR: a "template_tag" in yaml file is required '
+                                         f'for channel {channel}, algorithm "{algorithm}" !')
+                    if params.get("interpolate", False):
+                        raise NotImplementedError("interpolate: True is not on the GPU path")
+                    csd_tag = params.get("csd_tag", "default")
+                    coupling = params.get("coupling", "AC")
+                    peaks = params.get("ignored_frequency_peaks")
+                    if peaks is not None and not isinstance(peaks, list):
+                        peaks = [peaks]
+                    harm = bool(params.get("ignore_harmonics", False)) if peaks else False
+                    skey = (params["template_tag"], csd_tag, coupling,
+                            tuple(peaks) if peaks else None, harm,
+                            bool(params.get("integralnorm", False)))
+                    pending.append(("of", algorithm, base, skey, params, wmin, wmax, npre))
+                elif base in TD_ALGORITHMS:
+                    pending.append(("td", algorithm, base, None, params, wmin, wmax, npre))
+                elif any(p in base for p in OF_BASE_PREFIXES) or base == "energyabsorbed":
+                    raise NotImplementedError(
+                        f'algorithm "{base}" is outside the of1x1 hot path of this engine')
+                else:
+                    raise ValueError(f'ERROR: Cannot find algorithm "{base}" anywhere. '
+                                     f"Check feature extractor exists!")
+            if not pending:
+                continue
+            plan = OFPlan(n_samples, nb_pre_plan, self._fs, max_batch=self._max_batch,
+                          device=self._device, engine=self._engine)
+            if len(self._channels) > 1 or len(idx) > 1 or w[0] != 1.0:
+                plan.set_channels(len(self._channels), idx, w)
+            cols = []
+            for kind, algorithm, base, skey, params, wmin, wmax, npre in pending:
+                if kind == "of":
+                    if skey not in slots:
+                        slot = len(slots)
+                        tag, csd_tag, coupling, peaks, harm, inorm = skey
+                        # filter lookup uses the first physical channel of the expression
+                        fchan = channel if channel in self._filter_data._filter_data else names[0]
+                        template, _, tmeta = self._filter_data.get_template(
+                            fchan, tag=tag, return_metadata=True)
+                        csd, _, cmeta = self._filter_data.get_csd(
+                            fchan, tag=csd_tag, fold=False, return_metadata=True)
+                        if "sample_rate" in cmeta and cmeta["sample_rate"] != self._fs:
+                            raise ValueError(f"Sample rate is not consistent between raw "
+                                             f"data and csd for channel {channel}!")
+                        if n_samples != csd.shape[-1]:
+                            raise ValueError(
+                                f"Number of samples is not consistent between raw data "
+                                f"(={n_samples}) and csd (={csd.shape[-1]})for channel "
+                                f"{channel}, algorithm {algorithm}!")
+                        if n_samples != template.shape[-1]:
+                            raise ValueError(
+                                f'Number of samples is not consistent between raw data and '
+                                f'template ("{tag}") for channel {channel}, algorithm '
+                                f"{algorithm}!")
+                        pre_t = int(tmeta.get("nb_pretrigger_samples", npre))
+                        if pre_t != nb_pre_plan:
+                            raise ValueError("ERROR: template pretrigger differs from the "
+                                             "trace pretrigger")
+                        tables = build_filter(template, csd, self._fs, pre_t, coupling,
+                                              list(peaks) if peaks else None, harm, inorm)
+                        plan.set_filter(slot, tables)
+                        slots[skey] = slot
+                    slot = slots[skey]
+                    skind, qtys = OF_ALGORITHMS[base]
+                    fcut = float(params.get("lowchi2_fcutoff", 10000))
+                    if base == "of1x1_constrained":
+                        lo, hi = search_range(n_samples, nb_pre_plan, self._fs,
+                                              params.get("window_min_from_trig_usec"),
+                                              params.get("window_max_from_trig_usec"),
+                                              wmin, wmax, self._policy)
+                        sid = plan.add_search(slot, "delay", lo, hi,
+                                              bool(params.get("lgc_outside_window", False)),
+                                              fcut)
+                    else:
+                        sid = plan.add_search(slot, skind, lowchi2_fcutoff=fcut)
+                    cols.append(("of", slot, sid, qtys, algorithm))
+                else:
+                    hi = wmax              # end-exclusive slice trace[wmin:wmax]
+                    key = (wmin, hi)
+                    if key not in td_windows:
+                        td_windows[key] = plan.add_tdwindow(wmin, hi)
+                    cols.append(("td", td_windows[key], base, algorithm))
+            for c in cols:
+                if c[0] == "of":
+                    _, slot, sid, qtys, algorithm = c
+                    off = plan.search_offset(slot, sid)
+                    for q in qtys:
+                        cp.columns.append((f"{q}_{algorithm}_{feature_channel}",
+                                           off + _lib.COL[q]))
+                else:
+                    _, wid, base, algorithm = c
+                    off = plan.tdwindow_offset(wid)
+                    cp.columns.append((f"{algorithm}_{feature_channel}", off + _lib.TD[base]))
+            cp.plan = plan
+            plans[channel] = cp
+        self._plans = plans
+        self._compiled_n = n_samples
+
+    # ----------------------------------------------------------------- process
+    def columns(self):
+        return [name for cp in (self._plans or {}).values() for name, _ in cp.columns]
+
+    def process(self, traces, valid=None, as_dataframe=True):
+        """traces: float32 [B, C, N] (C = len(available_channels)) or [B, N] when there
+        is one channel; NumPy or CUDA tensor.  valid: optional [B] mask (0 -> every
+        feature of the event is -999999.0).  Returns a pandas DataFrame (or dict)."""
+        shape = tuple(traces.shape)
+        if len(shape) == 2:
+            if len(self._channels) != 1:
+                raise ValueError("ERROR: traces must be [B, C, N]")
+            traces = traces.reshape(shape[0], 1, shape[1])
+            shape = tuple(traces.shape)
+        if shape[1] != len(self._channels):
+            raise ValueError(f"ERROR: traces have {shape[1]} channels, expected "
+                             f"{len(self._channels)}")
+        if self._plans is None or self._compiled_n != shape[2]:
+            self._compile(shape[2])
+        result = {}
+        for channel, cp in self._plans.items():
+            tr = traces
+            if len(self._channels) == 1 and cp.plan.n_channels == 1:
+                tr = traces.reshape(shape[0], shape[2])
+            out = cp.plan.process(tr, valid=valid)
+            if not isinstance(out, np.ndarray):
+                out = out.cpu().numpy()
+            for name, off in cp.columns:
+                result[name] = out[:, off].astype(np.float64)
+        if as_dataframe:
+            import pandas as pd
+            return pd.DataFrame(result)
+        return result

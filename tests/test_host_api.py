@@ -1,0 +1,299 @@
+"""Host-side mirror of the reference interface: YAML surface, channel
+expressions, window indices, filter-file model (CPU), and on the GPU the
+FeatureExtractors static methods and the batched FeatureProcessing driver."""
+import numpy as np
+import pytest
+
+from detprocess_amd import FilterData, YamlConfig, synth, utils
+from detprocess_amd.ofbase import search_range
+
+FS = 1.25e6
+CHANS = ["Melange1pc1ch", "Melange025pcLeft", "Melange025pcRight", "Melange4pc1ch"]
+
+YAML = """
+filter_file: /path/to/filter_file.hdf5
+global:
+    trace_length_msec: 26.2144
+    pretrigger_length_msec: 13.1072
+Melange1pc1ch:
+    of1x1_nodelay:
+        run: True
+        lowchi2_fcutoff: 15000
+        template_tag: default
+        noise_tag: default
+    of1x1_unconstrained:
+        run: True
+        template_tag: default
+    of1x1_constrained:
+        run: True
+        window_min_from_trig_usec: -400
+        window_max_from_trig_usec: 400
+        template_tag: default
+        csd_tag: default
+    of1x1_glitch:
+        run: True
+        base_algorithm: of1x1_unconstrained
+        template_tag: glitch
+    baseline:
+        run: True
+        window_min_from_start_usec: 0
+        window_max_from_trig_usec: -2000
+    baseline_end:
+        run: True
+        base_algorithm: baseline
+        window_min_from_trig_usec: 2000
+        window_max_to_end_usec: 0
+    maximum:
+        run: True
+        window_min_from_trig_usec: -500
+        window_max_from_trig_usec: 500
+    minimum:
+        run: True
+        window_min_from_trig_usec: -500
+        window_max_from_trig_usec: 500
+    integral:
+        run: True
+        window_min_from_trig_usec: -10
+        window_max_from_trig_usec: 500
+    energyabsorbed:
+        run: False
+        i0: 88e-9
+Melange025pcLeft+Melange025pcRight:
+    feature_channel: MelangeSum
+    weight_Melange025pcLeft: 0.9
+    weight_Melange025pcRight: 1.1
+    of1x1_unconstrained:
+        run: True
+        template_tag: default
+    integral:
+        run: True
+Melange4pc1ch:
+    disable: True
+    baseline:
+        run: True
+"""
+
+
+def test_yaml_surface():
+    cfg = YamlConfig(YAML, CHANS, sample_rate=FS).get_config("feature")
+    assert cfg["overall"]["filter_file"] == "/path/to/filter_file.hdf5"
+    assert set(cfg["channels"]) == {"Melange1pc1ch", "Melange025pcLeft+Melange025pcRight"}
+    a = cfg["channels"]["Melange1pc1ch"]
+    assert "energyabsorbed" not in a                          # run: False dropped
+    assert a["of1x1_nodelay"]["csd_tag"] == "default"          # noise_tag renamed
+    assert a["of1x1_nodelay"]["nb_samples"] == 32768
+    assert a["of1x1_nodelay"]["nb_pretrigger_samples"] == 16384
+    assert cfg["traces_config"] == {(32768, 16384): ["Melange1pc1ch", "Melange025pcLeft",
+                                                     "Melange025pcRight"]}
+    assert cfg["weights"] == {"Melange025pcLeft+Melange025pcRight":
+                              {"weight_Melange025pcLeft": 0.9, "weight_Melange025pcRight": 1.1}}
+    assert cfg["channel_list"] == ["Melange1pc1ch", "Melange025pcLeft", "Melange025pcRight"]
+    # comma lists and 'all' expand; duplicates are an error; run is required
+    c2 = YamlConfig("A,B:\n  baseline:\n    run: True\n", ["A", "B"]).get_config("feature")
+    assert set(c2["channels"]) == {"A", "B"}
+    c3 = YamlConfig("all:\n  baseline:\n    run: True\n", ["A", "B", "C"]).get_config("feature")
+    assert set(c3["channels"]) == {"A", "B", "C"}
+    with pytest.raises(ValueError):
+        YamlConfig("A:\n  baseline:\n    run: True\n  baseline:\n    run: True\n", ["A"])
+    with pytest.raises(ValueError):
+        YamlConfig("A:\n  baseline:\n    window_min_index: 3\n", ["A"])
+    with pytest.raises(ValueError):
+        YamlConfig("global:\n  trace_length_samples: 100\nA:\n  baseline:\n    run: True\n", ["A"])
+    with pytest.raises(ValueError):
+        YamlConfig("A+Q:\n  baseline:\n    run: True\n", ["A", "B"]).get_config("feature")
+
+
+def test_split_channel_name():
+    s = utils.split_channel_name
+    assert s("A") == (["A"], None)
+    assert s("A+B", ["A", "B"]) == (["A", "B"], "+")
+    assert s("A|B", ["A", "B"]) == (["A", "B"], "|")
+    assert s("A,B", separator=",") == (["A", "B"], ",")
+    assert s("A-B", ["A", "B"]) == (["A", "B"], "-")
+    assert s("Det-1", ["Det-1", "Det-2"]) == (["Det-1"], None)
+    assert s("Det-1-Det-2", ["Det-1", "Det-2"])[0] == ["Det-1", "Det-2"]
+    with pytest.raises(ValueError):
+        s("A-B", separator="-")
+    with pytest.raises(ValueError):
+        s("A+Q", ["A", "B"])
+    with pytest.raises(ValueError):
+        s("A;B", ["A", "B"], separator=";")
+
+
+def test_search_range_policies():
+    assert search_range(32768, 16384, FS, -400, 400, 15884, 16884) == (15884, 16884)
+    assert search_range(32768, 16384, FS, None, None, 15884, 16884) == (15884, 16884)
+    assert search_range(32768, 16384, FS, None, None, 15884, 16884, "index") == (15884, 16885)
+    assert search_range(32768, 16384, FS, -10, 10) == (16371, 16397)     # floor / ceil of +-12.5
+    assert search_range(32768, 16384, FS) == (0, 32768)
+    assert search_range(32768, 16384, FS, -1e9, 1e9) == (0, 32768)
+
+
+def test_filterdata_model(tmp_path):
+    n = 4096
+    fd = FilterData()
+    t = synth.make_template(n, n // 2, FS)
+    J = synth.make_psd(n, FS)
+    f = np.fft.fftfreq(n, d=1 / FS)
+    fd.set_template("A", t, sample_rate=FS, pretrigger_length_samples=n // 2, tag="default")
+    fd.set_psd("A", J, f, sample_rate=FS, tag="default")
+    tt, time, meta = fd.get_template("A", return_metadata=True)
+    assert np.array_equal(tt, t) and meta["nb_pretrigger_samples"] == n // 2
+    assert time[n // 2] == 0 and time[0] == pytest.approx(-(n // 2) / FS)
+    csd, freqs, m = fd.get_csd("A", fold=False, return_metadata=True)
+    assert np.array_equal(csd, J) and m["sample_rate"] == FS
+    pf, ff = fd.get_psd("A", fold=True)[:2]
+    assert pf.shape[0] == n // 2 + 1 and pf[1] == pytest.approx(2 * J[1]) and pf[0] == J[0]
+    with pytest.raises(ValueError):
+        fd.set_psd("A", J[: n // 2 + 1], np.fft.rfftfreq(n, d=1 / FS))     # folded: refused
+    with pytest.raises(ValueError):
+        fd.get_template("B")
+    with pytest.raises(ValueError):
+        fd.get_template("A", tag="nope")
+    fd.save_npz(tmp_path / "filt.npz")
+    fd2 = FilterData()
+    fd2.load_npz(tmp_path / "filt.npz")
+    t2, _, m2 = fd2.get_template("A", return_metadata=True)
+    assert np.array_equal(t2, t) and m2["nb_pretrigger_samples"] == n // 2
+
+
+# ------------------------------------------------------------------- GPU side
+def _filter_data(n, pre):
+    fd = FilterData()
+    f = np.fft.fftfreq(n, d=1 / FS)
+    J = synth.make_psd(n, FS)
+    for ch in CHANS + ["Melange025pcLeft+Melange025pcRight"]:
+        fd.set_template(ch, synth.make_template(n, pre, FS, "pulse"), sample_rate=FS,
+                        pretrigger_length_samples=pre, tag="default")
+        fd.set_template(ch, synth.make_template(n, pre, FS, "glitch"), sample_rate=FS,
+                        pretrigger_length_samples=pre, tag="glitch")
+        fd.set_psd(ch, J, f, sample_rate=FS, tag="default")
+    return fd, J
+
+
+@pytest.mark.gpu
+def test_feature_extractors_static_methods():
+    from detprocess_amd import FeatureExtractors as FE, OFBase
+    from oracle import of1x1 as orc
+    n, pre = 32768, 16384
+    tmpl = synth.make_template(n, pre, FS)
+    J = synth.make_psd(n, FS)
+    filt = orc.OFFilter(tmpl, J, FS, pre)
+    x, _, _ = synth.make_traces(5, tmpl, J, FS, filt.ampres, seed=21)
+    x32 = x.astype(np.float32)
+    ob = OFBase(FS)
+    ob.set_csd("chanA", J, coupling="AC")
+    ob.add_template("chanA", tmpl, template_tag="default", pretrigger_samples=pre)
+    assert ob.phi("chanA", "default") is None
+    ob.calc_phi("chanA", "default")
+    assert ob.phi("chanA", "default") is not None
+    # no signal -> sentinel (algorithms.py:398-407)
+    r = FE.of1x1_unconstrained("chanA", ob, template_tag="default")
+    assert r == {"amp_of1x1_unconstrained": -999999.0, "t0_of1x1_unconstrained": -999999.0,
+                 "chi2_of1x1_unconstrained": -999999.0, "lowchi2_of1x1_unconstrained": -999999.0}
+    with pytest.raises(ValueError):
+        FE.of1x1_nodelay("chanA", ob)                       # template tag required
+    # single event -> scalars
+    ob.update_signal("chanA", x32[0], calc_fft=True)
+    ob.calc_signal_filt("chanA")
+    ob.calc_signal_filt_td("chanA")
+    r = FE.of1x1_constrained("chanA", ob, template_tag="default",
+                             window_min_from_trig_usec=-400, window_max_from_trig_usec=400,
+                             window_min_index=15884, window_max_index=16884,
+                             feature_base_name="myof", fs=FS, nb_samples=n, junk=1)
+    ref = orc.of1x1_withdelay(filt, x32[0].astype(np.float64), -400, 400)
+    assert set(r) == {f"{q}_myof" for q in ("amp", "t0", "chi2", "lowchi2", "chi2nopulse",
+                                            "ampres", "timeres")}
+    assert isinstance(r["amp_myof"], float)
+    assert r["amp_myof"] == pytest.approx(ref["amp"], rel=2e-5, abs=1e-4 * filt.ampres)
+    assert r["t0_myof"] == pytest.approx(ref["t0"], rel=1e-6, abs=1e-12)
+    assert r["chi2_myof"] == pytest.approx(ref["chi2"], rel=2e-5, abs=2e-6 * ref["chi2nopulse"])
+    assert r["ampres_myof"] == pytest.approx(filt.ampres, rel=1e-6)
+    # batch -> arrays
+    ob.clear_signal()
+    assert not ob.is_signal_stored("chanA")
+    ob.update_signal("chanA", x32)
+    r = FE.of1x1_nodelay("chanA", ob, template_tag="default", lowchi2_fcutoff=15000)
+    refn = orc.process_events(filt, x32.astype(np.float64), "nodelay", lowchi2_fcutoff=15000)
+    assert np.allclose(r["amp_of1x1_nodelay"], refn["amp"], rtol=2e-5, atol=1e-4 * filt.ampres)
+    assert np.allclose(r["lowchi2_of1x1_nodelay"], refn["lowchi2"], rtol=2e-5, atol=1e-2)
+    assert "t0_of1x1_nodelay" not in r                      # algorithms.py:344-348
+    # trace family
+    tr = x32[1]
+    assert FE.baseline(tr, 100, 5000)["baseline"] == pytest.approx(
+        float(orc.baseline(tr.astype(np.float64), 100, 5000)), rel=1e-4, abs=1e-12)
+    assert FE.integral(tr, FS, 16000, 17000, feature_base_name="int2")["int2"] == pytest.approx(
+        float(orc.integral(tr.astype(np.float64), FS, 16000, 17000)), rel=1e-4, abs=1e-15)
+    assert FE.maximum(tr)["maximum"] == float(tr[:-1].max())       # default max = N-1, exclusive
+    assert FE.minimum(x32)["minimum"].shape == (5,)
+    assert FE.baseline(np.array([]))["baseline"] == -999999.0
+    odd = np.arange(1001, dtype=np.float32)
+    assert FE.maximum(odd)["maximum"] == 999.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["auto", "rocfft"])
+def test_feature_processing_batch_driver(engine):
+    from detprocess_amd import FeatureProcessing
+    from oracle import of1x1 as orc
+    n, pre, B = 32768, 16384, 9
+    fd, J = _filter_data(n, pre)
+    tmpl = synth.make_template(n, pre, FS)
+    filt = orc.OFFilter(tmpl, J, FS, pre)
+    filt_g = orc.OFFilter(synth.make_template(n, pre, FS, "glitch"), J, FS, pre)
+    ev, _, _ = synth.make_traces(B * 4, tmpl, J, FS, filt.ampres, seed=31)
+    ev = ev.reshape(B, 4, n).astype(np.float32)
+    fp = FeatureProcessing(YAML, fd, CHANS, FS, engine=engine)
+    valid = np.ones(B, dtype=np.uint8)
+    valid[4] = 0
+    df = fp.process(ev, valid=valid)
+    want_cols = {"amp_of1x1_nodelay_Melange1pc1ch", "chi2_of1x1_nodelay_Melange1pc1ch",
+                 "lowchi2_of1x1_nodelay_Melange1pc1ch", "t0_of1x1_unconstrained_Melange1pc1ch",
+                 "timeres_of1x1_constrained_Melange1pc1ch", "amp_of1x1_glitch_Melange1pc1ch",
+                 "baseline_Melange1pc1ch", "baseline_end_Melange1pc1ch",
+                 "maximum_Melange1pc1ch", "minimum_Melange1pc1ch", "integral_Melange1pc1ch",
+                 "amp_of1x1_unconstrained_MelangeSum", "integral_MelangeSum"}
+    assert want_cols <= set(df.columns)
+    assert "t0_of1x1_nodelay_Melange1pc1ch" not in df.columns
+    assert (df.iloc[4] == -999999.0).all()
+    ok = valid.astype(bool)
+    x = ev[:, 0, :].astype(np.float64)
+    r = orc.process_events(filt, x, "unconstrained")
+    assert np.array_equal(np.round(df["t0_of1x1_unconstrained_Melange1pc1ch"][ok] * FS),
+                          (r["index"] - pre)[ok])
+    assert np.allclose(df["amp_of1x1_unconstrained_Melange1pc1ch"][ok], r["amp"][ok], rtol=2e-5,
+                       atol=1e-4 * filt.ampres)
+    rc = orc.process_events(filt, x, "constrained", window_min_from_trig_usec=-400,
+                            window_max_from_trig_usec=400)
+    assert np.allclose(df["amp_of1x1_constrained_Melange1pc1ch"][ok], rc["amp"][ok], rtol=2e-5,
+                       atol=1e-4 * filt.ampres)
+    rn = orc.process_events(filt, x, "nodelay", lowchi2_fcutoff=15000)
+    assert np.allclose(df["lowchi2_of1x1_nodelay_Melange1pc1ch"][ok], rn["lowchi2"][ok],
+                       rtol=2e-5, atol=2e-6 * r["chi2nopulse"][ok].max())
+    rg = orc.process_events(filt_g, x, "unconstrained")
+    assert np.allclose(df["amp_of1x1_glitch_Melange1pc1ch"][ok], rg["amp"][ok], rtol=2e-5,
+                       atol=1e-4 * filt_g.ampres)
+    # trace features with the reference's window arithmetic and end-exclusive slices
+    lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_start_usec=0,
+                                    window_max_from_trig_usec=-2000)
+    assert np.allclose(df["baseline_Melange1pc1ch"][ok], orc.baseline(x, lo, hi)[ok], rtol=1e-4,
+                       atol=1e-6 * np.abs(x).max())
+    lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_trig_usec=2000,
+                                    window_max_to_end_usec=0)
+    assert np.allclose(df["baseline_end_Melange1pc1ch"][ok], orc.baseline(x, lo, hi)[ok],
+                       rtol=1e-4, atol=1e-6 * np.abs(x).max())
+    lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_trig_usec=-500,
+                                    window_max_from_trig_usec=500)
+    assert np.array_equal(df["maximum_Melange1pc1ch"][ok],
+                          orc.maximum(x, lo, hi)[ok].astype(np.float32).astype(np.float64))
+    lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_trig_usec=-10,
+                                    window_max_from_trig_usec=500)
+    assert np.allclose(df["integral_Melange1pc1ch"][ok], orc.integral(x, FS, lo, hi)[ok],
+                       rtol=1e-4, atol=1e-6 * np.abs(x).max() * (hi - lo) / FS)
+    # summed channel with weights
+    xs = 0.9 * ev[:, 1, :].astype(np.float64) + 1.1 * ev[:, 2, :].astype(np.float64)
+    rs = orc.process_events(filt, xs, "unconstrained")
+    assert np.allclose(df["amp_of1x1_unconstrained_MelangeSum"][ok], rs["amp"][ok], rtol=3e-5,
+                       atol=2e-4 * filt.ampres)
+    assert np.allclose(df["integral_MelangeSum"][ok], orc.integral(xs, FS, 0, n - 1)[ok],
+                       rtol=1e-4, atol=1e-6 * np.abs(xs).max() * n / FS)
