@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libofx.so")
+LIB_PATH = os.environ.get("OFX_LIB", os.path.join(_HERE, "libofx.so"))
 
 OK = 0
 MEM_HOST, MEM_DEVICE = 0, 1

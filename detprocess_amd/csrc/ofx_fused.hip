@@ -1,21 +1,26 @@
-// ofx_fused.hip -- FUSED engine: one persistent workgroup per CU carries a whole
-// trace through   load -> real FFT -> optimal filter + chi2_0 -> inverse FFT ->
-// arg-max / chi2 / low-frequency chi2 -> one output row,
-// touching HBM once per sample.
+// ofx_fused.hip -- FUSED engine: a persistent workgroup carries a whole trace through
+//   load -> real FFT -> optimal filter + chi2_0 -> inverse FFT -> arg-max / chi2 /
+//   low-frequency chi2 -> one output row,   touching HBM once per sample
+// (SURVEY.md section 7 step 5).
 //
-// Geometry for N = 32768 real samples (M = N/2 = 16384 complex, z[m] = x[2m] +
-// i x[2m+1]):  512 threads x 32 complex values in VGPRs, M = 32 x 32 x 16.
+// Geometry for N = 32768 real samples (M = N/2 = 16384 packed complex points,
+// z[m] = x[2m] + i x[2m+1]); the whole trace lives in registers, M = 32 x 32 x 16:
 //   m = 512 n1 + 16 n2 + n3      k = k1 + 32 k2 + 1024 k3
-//   F1: thread t = n' = 16 n2 + n3, radix-32 over n1 -> k1, twiddle w_M^{n' k1}
+//   F1: virtual thread t = n' = 16 n2 + n3, radix-32 over n1 -> k1, x w_M^{n' k1}
 //   E1: LDS exchange D1[k1][n']            (row stride 513: conflict-free)
-//   F2: thread u = 32 n3 + k1, radix-32 over n2 -> k2, twiddle w_512^{n3 k2}
+//   F2: virtual thread u = 32 n3 + k1, radix-32 over n2 -> k2, x w_512^{n3 k2}
 //   E2: LDS exchange D2[k1 + 32 k2][n3]    (row stride 17: conflict-free)
-//   F3: thread v owns the two 16-point blocks k_low = v and its Hermitian
+//   F3: virtual thread v owns the two 16-point blocks k_low = v and its Hermitian
 //       partner 1024 - v (v = 0: the two self-paired blocks 0 and 512), so the
 //       real-FFT unpack, the filter multiply, chi2_0 and the re-pack for the
 //       inverse need NO exchange:  (Z_k, Z_{M-k}) live in the same thread.
 //   I3 / E3 / I2 / E4 / I1 mirror F3 / E2 / F2 / E1 / F1 with conjugate twiddles.
-// After I1 thread t holds A(n) for the 64 lags n = 1024 n1 + 2 t + {0,1}.
+// After I1 virtual thread t holds A(n) for the 64 lags n = 1024 n1 + 2 t + {0,1}.
+//
+// 512 virtual threads x 32 complex values.  A hardware thread carries VT of them
+// (VT = 2: 256-thread workgroups, 64 complex = 128 VGPRs of data, two workgroups
+// resident per CU so that one computes while the other sits in LDS / barrier / HBM
+// waits, and every thread has two independent instruction streams).
 #include <cmath>
 #include <cstring>
 
@@ -27,24 +32,28 @@ using namespace ofxfft;
 
 namespace {
 
+#ifndef OFX_VT
+#define OFX_VT 2
+#endif
+constexpr int VT = OFX_VT;         // virtual threads per hardware thread
 constexpr int FN = 32768;          // samples
 constexpr int FM = 16384;          // packed complex points
-constexpr int FT = 512;            // threads per workgroup
-#ifndef OFX_WG_PER_CU
-#define OFX_WG_PER_CU 1
-#endif
-constexpr int WG_PER_CU = OFX_WG_PER_CU;   // workgroups resident per CU (2: one computes
-                                           // while the other waits on LDS / barriers / HBM)
-constexpr int LD1 = 513;           // D1 row stride (floats)
-constexpr int LD2 = 17;            // D2 row stride (floats)
-constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 floats >= 32*513, >= 16384
+constexpr int FV = 512;            // virtual threads
+constexpr int FT = FV / VT;        // hardware threads per workgroup
+constexpr int WG_PER_CU = VT;      // workgroups resident per CU
+constexpr int NV = 32 * VT;        // complex values per hardware thread
+constexpr int LD1 = 513;           // D1 row stride (elements)
+constexpr int LD2 = 17;            // D2 row stride (elements)
+constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 >= 32*513, >= 16384
 constexpr int NLOW_MAX = 512;
 constexpr int NWAVE = FT / OFX_WAVE;
 
-// LDS: real and imaginary parts go through the exchange buffer separately, so a
-// workgroup needs 68 KiB (not 136) and two of them fit the CU's 160 KiB.
+// With two workgroups per CU, real and imaginary parts go through the exchange
+// buffer separately: 68 KiB per workgroup instead of 136.
+constexpr bool SPLIT_EXCHANGE = (WG_PER_CU > 1);
+
 struct FusedLds {
-    float xb[XBUF_ELEMS];          // 69,632 B   exchange buffer / half lag dump
+    float xb[SPLIT_EXCHANGE ? XBUF_ELEMS : 2 * XBUF_ELEMS];   // exchange buffer / lag dump
     float2 t2[512];                //  4,096 B   w_512^{n3 k2}, index k2*16+n3
     float2 xlow[NLOW_MAX + 8];     //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
@@ -55,7 +64,7 @@ struct FusedLds {
 static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
 
 struct FusedTabs {
-    const float2* t1;     // [16][512][2]  (w_M^{n' 2kq}, w_M^{n' (2kq+1)}) as float4 rows
+    const float2* t1;     // [16][512] float4 rows (w_M^{n' 2kq}, w_M^{n' (2kq+1)})
     const float2* t2;     // [32][16]   w_512^{n3 k2}
     const float4* midA;   // [16][512]  (t_k.x, t_k.y, W_k.x/2, W_k.y/2)
     const float4* midB;   // [16][512]  (conj(W_p).x/2, conj(W_p).y/2, g_k', g_p')
@@ -73,6 +82,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+#ifdef ABL_NOTAB
+    return make_float4(0.5f + voff * 1e-9f, 0.25f, 0.125f + soff * 1e-9f, 0.7f);
+#endif
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
@@ -84,9 +96,9 @@ __device__ __forceinline__ float2 buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, in
 
 // ---- the pairwise middle step on one (Z_k, Z_p) slot -------------------------
 // in : zk = Z_k, zp = Z_p (p = M - k)      out: zk = Z'_k, zp = Z'_p
-// returns the chi2_0 contribution; xk2 = 2 X_k, xp2 = 2 conj(X_p).
+// returns the chi2_0 contribution; xk2 = 2 X_k.
 __device__ __forceinline__ float mid_slot(float2& zk, float2& zp, const float4 ta,
-                                          const float4 tb, float2& xk2, float2& xp2) {
+                                          const float4 tb, float2& xk2) {
     const float2 t = make_float2(ta.x, ta.y);
     const float2 wk = make_float2(ta.z, ta.w);
     const float2 wp = make_float2(tb.x, tb.y);
@@ -94,8 +106,8 @@ __device__ __forceinline__ float mid_slot(float2& zk, float2& zp, const float4 t
     const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
     // s = i t w
     const float2 s = make_float2(-fmaf(t.x, w.y, t.y * w.x), fmaf(t.x, w.x, -t.y * w.y));
-    xk2 = make_float2(u.x - s.x, u.y - s.y);
-    xp2 = make_float2(u.x + s.x, u.y + s.y);
+    xk2 = make_float2(u.x - s.x, u.y - s.y);                 // 2 X_k
+    const float2 xp2 = make_float2(u.x + s.x, u.y + s.y);    // 2 conj(X_p)
     float chi = tb.z * fmaf(xk2.x, xk2.x, xk2.y * xk2.y);
     chi = fmaf(tb.w, fmaf(xp2.x, xp2.x, xp2.y * xp2.y), chi);
     const float2 yk = cmul(xk2, wk);
@@ -113,53 +125,53 @@ __device__ __forceinline__ float2 sel(bool c, float2 a, float2 b) {
     return make_float2(c ? a.x : b.x, c ? a.y : b.y);
 }
 
-// Middle step over the 32 values of a thread.  A = d[0..15] (block k_low = v),
-// B = d[16..31] (partner block).  Generic thread: slot j pairs (A[j], B[15-j]).
-// Thread 0 (blocks 0 and 512, both self-paired) is brought to the same slot
-// shape by a register permutation (perm_in / perm_out), applied only in the
-// wave that holds it.
-__device__ __forceinline__ void perm_in(float2 (&d)[32], int v) {
-    const bool z = (v == 0);
+// Middle step over the 32 values of a virtual thread at d[O .. O+32).
+// A = d[O+0..15] (block k_low = v), B = d[O+16..31] (partner block).  Generic: slot j
+// pairs (A[j], B[15-j]).  Virtual thread 0 (blocks 0 and 512, both self-paired) is
+// brought to the same slot shape by a register permutation (perm_in / perm_out),
+// applied only in the wave that holds it.
+template <int O>
+__device__ __forceinline__ void perm_in(float2 (&d)[NV], bool z) {
     // genA = [A0[0..7], B0[0..7]] ; genB = [B0[8..15], A0[9..15], A0[0]]
     float2 n[32];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) n[j] = d[j];
+    for (int j = 0; j < 8; ++j) n[j] = d[O + j];
 #pragma unroll
-    for (int j = 8; j < 16; ++j) n[j] = sel(z, d[16 + j - 8], d[j]);
+    for (int j = 8; j < 16; ++j) n[j] = sel(z, d[O + 16 + j - 8], d[O + j]);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[16 + 8 + i], d[16 + i]);
+    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[O + 16 + 8 + i], d[O + 16 + i]);
 #pragma unroll
-    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[(i + 1) % 16], d[16 + i]);
+    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[O + (i + 1) % 16], d[O + 16 + i]);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) d[j] = n[j];
+    for (int j = 0; j < 32; ++j) d[O + j] = n[j];
 }
 
-__device__ __forceinline__ float perm_out(float2 (&d)[32], int v, float2 a8,
+template <int O>
+__device__ __forceinline__ float perm_out(float2 (&d)[NV], bool z, float2 a8,
                                           const FusedTabs& tabs, float chi) {
-    const bool z = (v == 0);
-    // self-paired bin k = M/2 (thread 0, A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
+    // self-paired bin k = M/2 (virtual thread 0, A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
     const float2 zq = cmulc(a8, tabs.wq);
     if (z) chi = fmaf(2.0f * tabs.gq, fmaf(a8.x, a8.x, a8.y * a8.y), chi);
     float2 n[32];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) n[j] = d[j];
+    for (int j = 0; j < 8; ++j) n[j] = d[O + j];
     // A0[8] special, A0[9..15] = genB[8..14], A0[0] = genA[0] (genB[15] discarded)
-    n[8] = sel(z, make_float2(2.0f * zq.x, 2.0f * zq.y), d[8]);
+    n[8] = sel(z, make_float2(2.0f * zq.x, 2.0f * zq.y), d[O + 8]);
 #pragma unroll
-    for (int j = 9; j < 16; ++j) n[j] = sel(z, d[16 + j - 1], d[j]);
+    for (int j = 9; j < 16; ++j) n[j] = sel(z, d[O + 16 + j - 1], d[O + j]);
     // B0[0..7] = genA[8..15] ; B0[8..15] = genB[0..7]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[8 + i], d[16 + i]);
+    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[O + 8 + i], d[O + 16 + i]);
 #pragma unroll
-    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[16 + i - 8], d[16 + i]);
+    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[O + 16 + i - 8], d[O + 16 + i]);
 #pragma unroll
-    for (int j = 0; j < 32; ++j) d[j] = n[j];
+    for (int j = 0; j < 32; ++j) d[O + j] = n[j];
     return chi;
 }
 
-// 16 pair slots; table rows are software-pipelined two slots ahead so that at
-// most three rows (24 VGPRs) are in flight.
-__device__ __forceinline__ float middle_slots(float2 (&d)[32], __amdgpu_buffer_rsrc_t rmid,
+// 16 pair slots; table rows are software-pipelined two slots ahead.
+template <int O>
+__device__ __forceinline__ float middle_slots(float2 (&d)[NV], __amdgpu_buffer_rsrc_t rmid,
                                               int v, FusedLds& L) {
     // rmid covers [midA: 16 rows][midB: 16 rows], 8 KiB per row
     float4 ta[3], tb[3];
@@ -175,75 +187,62 @@ __device__ __forceinline__ float middle_slots(float2 (&d)[32], __amdgpu_buffer_r
             ta[(j + 2) % 3] = buf_ld4(rmid, vo, (j + 2) * 8192);
             tb[(j + 2) % 3] = buf_ld4(rmid, vo, (16 + j + 2) * 8192);
         }
-#ifndef NO_SB
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        float2 xk2, xp2;
-        chi += mid_slot(d[j], d[16 + 15 - j], ta[j % 3], tb[j % 3], xk2, xp2);
+        float2 xk2;
+        chi += mid_slot(d[O + j], d[O + 16 + 15 - j], ta[j % 3], tb[j % 3], xk2);
         if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
-#ifndef NO_SB
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
     return chi;
 }
 
 // Inter-stage twiddles w_M^{n' k1} (F1: multiply, I1: multiply by the conjugate).
-// t1q[kq][tid] packs (w^{2kq}, w^{2kq+1}); rows are streamed in groups of four
-// (8 twiddles, 16 VGPRs), the next group in flight while one is applied.
-struct T1Group {
-    float4 q[4];
-};
-__device__ __forceinline__ T1Group t1_load(__amdgpu_buffer_rsrc_t t1q, int tid, int g) {
-    T1Group r;
+// t1q[kq][vt] packs (w^{2kq}, w^{2kq+1}); rows are streamed in groups of four.
+template <bool CONJ, int O>
+__device__ __forceinline__ void t1_apply(float2 (&d)[NV], __amdgpu_buffer_rsrc_t t1q, int vt) {
+    float4 cur[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r.q[c] = buf_ld4(t1q, tid * 16, (4 * g + c) * 8192);
-    return r;
-}
-template <bool CONJ>
-__device__ __forceinline__ void t1_apply(float2 (&d)[32], __amdgpu_buffer_rsrc_t t1q, int tid,
-                                         T1Group cur) {
+    for (int c = 0; c < 4; ++c) cur[c] = buf_ld4(t1q, vt * 16, c * 8192);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        T1Group nxt;
-        if (g < 3) nxt = t1_load(t1q, tid, g + 1);
-        __builtin_amdgcn_sched_barrier(0);
+        float4 nxt[4];
+        if (g < 3) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) nxt[c] = buf_ld4(t1q, vt * 16, (4 * (g + 1) + c) * 8192);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k1 = 8 * g + 2 * c;
-            const float2 w0 = make_float2(cur.q[c].x, cur.q[c].y);
-            const float2 w1 = make_float2(cur.q[c].z, cur.q[c].w);
-            if (k1 != 0) d[k1] = CONJ ? cmulc(d[k1], w0) : cmul(d[k1], w0);
-            d[k1 + 1] = CONJ ? cmulc(d[k1 + 1], w1) : cmul(d[k1 + 1], w1);
+            const float2 w0 = make_float2(cur[c].x, cur[c].y);
+            const float2 w1 = make_float2(cur[c].z, cur[c].w);
+            if (k1 != 0) d[O + k1] = CONJ ? cmulc(d[O + k1], w0) : cmul(d[O + k1], w0);
+            d[O + k1 + 1] = CONJ ? cmulc(d[O + k1 + 1], w1) : cmul(d[O + k1 + 1], w1);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (g < 3) cur = nxt;
+        if (g < 3) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+        }
     }
 }
 
-// LDS exchange of 32 complex values per thread, real parts then imaginary parts.
-template <class WI, class RI>
-__device__ __forceinline__ void exchange(float2 (&d)[32], float* xb, WI widx, RI ridx) {
-    __syncthreads();                       // earlier readers of xb are done
-#pragma unroll
-    for (int j = 0; j < 32; ++j) xb[widx(j)] = d[j].x;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 32; ++j) d[j].x = xb[ridx(j)];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 32; ++j) xb[widx(j)] = d[j].y;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 32; ++j) d[j].y = xb[ridx(j)];
-}
+// Roles and LDS index maps of one virtual thread.
+struct Roles {
+    int vt, n3u, k1u, kB;
+    __device__ __forceinline__ explicit Roles(int v) {
+        vt = v;
+        n3u = v >> 5; k1u = v & 31;          // F2 / I2 role
+        kB = partner_block(v);               // F3 / I3 role
+    }
+    __device__ __forceinline__ int e1w(int k1) const { return k1 * LD1 + vt; }
+    __device__ __forceinline__ int e1r(int n2) const { return k1u * LD1 + 16 * n2 + n3u; }
+    __device__ __forceinline__ int e2w(int k2) const { return (k1u + 32 * k2) * LD2 + n3u; }
+    __device__ __forceinline__ int e2r(int j) const { return (j < 16 ? vt : kB) * LD2 + (j & 15); }
+};
 
 // ------------------------------------------------------------------ the kernel
 // FEAT bit 0: plan has searches that are not full-range (scan the LDS lag dump)
 // FEAT bit 1: plan has time-domain windows
 // FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
 template <int FEAT>
-__global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
+__global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
                                                  const float* __restrict__ traces,
                                                  const uint8_t* __restrict__ valid,
                                                  long long n_traces, float* __restrict__ out) {
@@ -251,8 +250,6 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
     FusedLds& L = *reinterpret_cast<FusedLds*>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int n3u = tid >> 5, k1u = tid & 31;       // F2 / I2 role
-    const int kB = partner_block(tid);              // F3 / I3 role
     const int pre = pd.pre;
     const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 32 * 512 * 8);
     const __amdgpu_buffer_rsrc_t rmid = make_rsrc(tabs.midA, 2 * 16 * 512 * 16);
@@ -260,43 +257,98 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
     for (int i = tid; i < 512; i += FT) L.t2[i] = tabs.t2[i];
 
     const size_t ev_stride = (size_t)pd.n_channels * FN;
-    float2 d[32];
+    float2 d[NV];
 
-    auto e1w = [&](int k1) { return k1 * LD1 + tid; };
-    auto e1r = [&](int n2) { return k1u * LD1 + 16 * n2 + n3u; };
-    auto e2w = [&](int k2) { return (k1u + 32 * k2) * LD2 + n3u; };
-    auto e2r = [&](int j) { return (j < 16 ? tid : kB) * LD2 + (j & 15); };
+    // LDS exchange of the NV values of a thread; widx / ridx map (role h, value j) to
+    // an element index.  SPLIT: real parts then imaginary parts through the same buffer.
+    auto exchange = [&](auto widx, auto ridx) {
+#ifdef ABL_NOEXCH
+        return;
+#endif
+        __syncthreads();                       // earlier readers of xb are done
+        if constexpr (!SPLIT_EXCHANGE) {
+            float2* xc = reinterpret_cast<float2*>(L.xb);
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) xc[widx(h, j)] = d[32 * h + j];
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) d[32 * h + j] = xc[ridx(h, j)];
+        } else {
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) L.xb[widx(h, j)] = d[32 * h + j].x;
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) d[32 * h + j].x = L.xb[ridx(h, j)];
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) L.xb[widx(h, j)] = d[32 * h + j].y;
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j) d[32 * h + j].y = L.xb[ridx(h, j)];
+        }
+    };
 
+    // Trace load into the register file (virtual thread vt reads z[512 n1 + vt]).
+    auto load_trace = [&](long long bb) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const float* e = traces + (size_t)bb * ev_stride;
+        if constexpr (FEAT & 4) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) d[j] = make_float2(0.f, 0.f);
+            for (int c = 0; c < pd.n_terms; ++c) {
+                const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + (size_t)pd.chan[c] * FN, FN * 4);
+                const float wgt = pd.weight[c];
+#pragma unroll
+                for (int h = 0; h < VT; ++h)
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) {
+                        const float2 s = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
+                        d[32 * h + n1].x = fmaf(wgt, s.x, d[32 * h + n1].x);
+                        d[32 * h + n1].y = fmaf(wgt, s.y, d[32 * h + n1].y);
+                    }
+            }
+        } else {
+            const __amdgpu_buffer_rsrc_t rz = make_rsrc(e, FN * 4);
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1)
+                    d[32 * h + n1] = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
+        }
+    };
+
+    // Software-pipelined trace load: the next trace is requested as soon as the
+    // registers of the current one are dead (after the arg-max), so that its HBM
+    // latency hides under the rest of the tail; `have` = d already holds trace b.
+    bool have = false;
     for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
         float* row = out + (size_t)b * pd.row;
         if (valid && !valid[b]) {
             for (int j = tid; j < pd.row; j += FT) row[j] = OFX_SENTINEL;
+            have = false;
             continue;
         }
-        // ------------------------------------------------------------- load
-        {
-            const float* e = traces + (size_t)b * ev_stride;
-            if constexpr (FEAT & 4) {
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) d[n1] = make_float2(0.f, 0.f);
-                for (int j = 0; j < pd.n_terms; ++j) {
-                    const float2* z =
-                        reinterpret_cast<const float2*>(e + (size_t)pd.chan[j] * FN);
-                    const float wgt = pd.weight[j];
-                    const __amdgpu_buffer_rsrc_t rz = make_rsrc(z, FN * 4);
-#pragma unroll
-                    for (int n1 = 0; n1 < 32; ++n1) {
-                        const float2 s = buf_ld2(rz, tid * 8, n1 * 4096);
-                        d[n1].x = fmaf(wgt, s.x, d[n1].x);
-                        d[n1].y = fmaf(wgt, s.y, d[n1].y);
-                    }
-                }
-            } else {
-                const __amdgpu_buffer_rsrc_t rz = make_rsrc(e, FN * 4);
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) d[n1] = buf_ld2(rz, tid * 8, n1 * 4096);
-            }
-        }
+        // Roles are re-derived from an opaque copy of tid every trace so that the LDS
+        // address arithmetic stays next to its use (LICM would hoist and spill it).
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const Roles R0(tl), R1(tl + FT);
+        auto RR = [&](int h) -> const Roles& { return h == 0 ? R0 : R1; };
+
+        if (!have) load_trace(b);               // cold start / after an invalid event
 
         // ------------------------------------------------ time-domain windows
         if constexpr (FEAT & 2) {
@@ -304,17 +356,19 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float s = 0.0f, mx = -INFINITY, mn = INFINITY, fl = 0.0f;
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) {
-                    const int n = 1024 * n1 + 2 * tid;
-                    const bool in0 = (n >= lo) && (n < hi);
-                    const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
-                    const float x0 = d[n1].x, x1 = d[n1].y;
-                    s += (in0 ? x0 : 0.0f) + (in1 ? x1 : 0.0f);
-                    mx = fmaxf(mx, fmaxf(in0 ? x0 : -INFINITY, in1 ? x1 : -INFINITY));
-                    mn = fminf(mn, fminf(in0 ? x0 : INFINITY, in1 ? x1 : INFINITY));
-                    if (n == lo || n == hi - 1) fl += x0;
-                    if (n + 1 == lo || n + 1 == hi - 1) fl += x1;
-                }
+                for (int h = 0; h < VT; ++h)
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) {
+                        const int n = 1024 * n1 + 2 * (tl + FT * h);
+                        const bool in0 = (n >= lo) && (n < hi);
+                        const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                        const float x0 = d[32 * h + n1].x, x1 = d[32 * h + n1].y;
+                        s += (in0 ? x0 : 0.0f) + (in1 ? x1 : 0.0f);
+                        mx = fmaxf(mx, fmaxf(in0 ? x0 : -INFINITY, in1 ? x1 : -INFINITY));
+                        mn = fminf(mn, fminf(in0 ? x0 : INFINITY, in1 ? x1 : INFINITY));
+                        if (n == lo || n == hi - 1) fl += x0;
+                        if (n + 1 == lo || n + 1 == hi - 1) fl += x1;
+                    }
                 if (hi - lo == 1) fl *= 2.0f;          // first == last sample
                 s = ofx_wave_sum(s);
                 mx = ofx_wave_max(mx);
@@ -340,52 +394,85 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
                 }
             }
         }
-        if (sd.n_search == 0) continue;
+        if (sd.n_search == 0) {
+            have = false;
+            continue;
+        }
 
         // ---------------------------------------------------------------- F1
-        {
-            const T1Group g0 = t1_load(t1q, tid, 0);
-            dft<32, -1>(d);
-            t1_apply<false>(d, t1q, tid, g0);
-        }
-        exchange(d, L.xb, e1w, e1r);
+        dft<32, -1, NV, 0>(d);
+        if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
+        t1_apply<false, 0>(d, t1q, tl);
+        if constexpr (VT == 2) t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT);
+        exchange([&](int h, int j) { return RR(h).e1w(j); },
+                 [&](int h, int j) { return RR(h).e1r(j); });
         // ---------------------------------------------------------------- F2
-        dft<32, -1>(d);
+        dft<32, -1, NV, 0>(d);
+        if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
 #pragma unroll
-        for (int k2 = 1; k2 < 32; ++k2) d[k2] = cmul(d[k2], L.t2[k2 * 16 + n3u]);
-        exchange(d, L.xb, e2w, e2r);
+        for (int h = 0; h < VT; ++h)
+#pragma unroll
+            for (int k2 = 1; k2 < 32; ++k2)
+                d[32 * h + k2] = cmul(d[32 * h + k2], L.t2[k2 * 16 + RR(h).n3u]);
+        exchange([&](int h, int j) { return RR(h).e2w(j); },
+                 [&](int h, int j) { return RR(h).e2r(j); });
         // ------------------------------------------- F3, middle, I3 (registers)
-        dft<16, -1, 32, 0>(d);
-        dft<16, -1, 32, 16>(d);
-        const float2 a8 = d[8];
-#ifndef NO_PERM
-        if (wave == 0) perm_in(d, tid);
-#endif
-        float chi0p = middle_slots(d, rmid, tid, L);
-#ifndef NO_PERM
-        if (wave == 0) chi0p = perm_out(d, tid, a8, tabs, chi0p);
-#endif
-        dft<16, +1, 32, 0>(d);
-        dft<16, +1, 32, 16>(d);
-        exchange(d, L.xb, e2r, e2w);
+        float chi0p = 0.0f;
+        {
+            dft<16, -1, NV, 0>(d);
+            dft<16, -1, NV, 16>(d);
+            const float2 a8 = d[8];
+            if (wave == 0) perm_in<0>(d, tl == 0);
+            chi0p += middle_slots<0>(d, rmid, tl, L);
+            if (wave == 0) chi0p = perm_out<0>(d, tl == 0, a8, tabs, chi0p);
+            dft<16, +1, NV, 0>(d);
+            dft<16, +1, NV, 16>(d);
+        }
+        if constexpr (VT == 2) {
+            constexpr int O = 32 * (VT - 1);
+            dft<16, -1, NV, O>(d);
+            dft<16, -1, NV, O + 16>(d);
+            chi0p += middle_slots<O>(d, rmid, tl + FT, L);
+            dft<16, +1, NV, O>(d);
+            dft<16, +1, NV, O + 16>(d);
+        }
+        int tl2 = tid;
+        asm volatile("" : "+v"(tl2));          // no CSE of addresses across the middle
+        const Roles Q0(tl2), Q1(tl2 + FT);
+        auto QQ = [&](int h) -> const Roles& { return h == 0 ? Q0 : Q1; };
+        exchange([&](int h, int j) { return QQ(h).e2r(j); },
+                 [&](int h, int j) { return QQ(h).e2w(j); });
         // ---------------------------------------------------------------- I2
 #pragma unroll
-        for (int k2 = 1; k2 < 32; ++k2) d[k2] = cmulc(d[k2], L.t2[k2 * 16 + n3u]);
-        dft<32, +1>(d);
-        {
-            const T1Group g0 = t1_load(t1q, tid, 0);
-            exchange(d, L.xb, e1r, e1w);
-            // ------------------------------------------------------------ I1
-            t1_apply<true>(d, t1q, tid, g0);
-        }
-        dft<32, +1>(d);
-        // d[n1] = (A(1024 n1 + 2 tid), A(1024 n1 + 2 tid + 1))
+        for (int h = 0; h < VT; ++h)
+#pragma unroll
+            for (int k2 = 1; k2 < 32; ++k2)
+                d[32 * h + k2] = cmulc(d[32 * h + k2], L.t2[k2 * 16 + QQ(h).n3u]);
+        dft<32, +1, NV, 0>(d);
+        if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
+        exchange([&](int h, int j) { return QQ(h).e1r(j); },
+                 [&](int h, int j) { return QQ(h).e1w(j); });
+        // ---------------------------------------------------------------- I1
+        t1_apply<true, 0>(d, t1q, tl2);
+        if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT);
+        dft<32, +1, NV, 0>(d);
+        if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
+        // d[32 h + n1] = (A(1024 n1 + 2 vt), A(1024 n1 + 2 vt + 1)),  vt = tid + FT h
 
+#ifdef ABL_NOTAIL
+        {
+            float acc = chi0p;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) acc += d[j].x + d[j].y;
+            if (acc == 1.2345f) row[0] = acc;
+            continue;
+        }
+#endif
         // ------------------------------------------------------------- tail
         float mloc = 0.0f;
 #pragma unroll
-        for (int n1 = 0; n1 < 32; ++n1)
-            mloc = fmaxf(mloc, fmaxf(d[n1].x * d[n1].x, d[n1].y * d[n1].y));
+        for (int j = 0; j < NV; ++j)
+            mloc = fmaxf(mloc, fmaxf(d[j].x * d[j].x, d[j].y * d[j].y));
         {
             const float wmax = ofx_wave_max(mloc);
             const float wchi = ofx_wave_sum(chi0p);
@@ -416,31 +503,45 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
         }
         if (any_full) {
             if (mloc == Mstar) {
-                int base = 2 * tid + pre;
-                asm volatile("" : "+v"(base));   // keep the 64 rolled indices out of LICM
+                int tb = tid;
+                asm volatile("" : "+v"(tb));   // keep the rolled indices out of LICM
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1) {
-                    const int i0 = (base + 1024 * n1) & (FN - 1);
-                    const int i1 = (base + 1024 * n1 + 1) & (FN - 1);
-                    if (d[n1].x * d[n1].x == Mstar && i0 < fullbest.idx) {
-                        fullbest.idx = i0; fullbest.amp = d[n1].x; fullbest.key = Mstar;
-                    }
-                    if (d[n1].y * d[n1].y == Mstar && i1 < fullbest.idx) {
-                        fullbest.idx = i1; fullbest.amp = d[n1].y; fullbest.key = Mstar;
+                for (int h = 0; h < VT; ++h) {
+                    const int base = 2 * (tb + FT * h) + pre;
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) {
+                        const float2 v = d[32 * h + n1];
+                        const int i0 = (base + 1024 * n1) & (FN - 1);
+                        const int i1 = (base + 1024 * n1 + 1) & (FN - 1);
+                        if (v.x * v.x == Mstar && i0 < fullbest.idx) {
+                            fullbest.idx = i0; fullbest.amp = v.x; fullbest.key = Mstar;
+                        }
+                        if (v.y * v.y == Mstar && i1 < fullbest.idx) {
+                            fullbest.idx = i1; fullbest.amp = v.y; fullbest.key = Mstar;
+                        }
                     }
                 }
             }
             fullbest = ofx_cand_block_reduce(fullbest, L.cand);
         }
 
-        // windowed / outside-window fits scan the lag dump, even lags then odd
+        // windowed / outside-window fits scan the lag dump
         if constexpr (FEAT & 1) {
             if (tid < OFX_MAX_SEARCHES) L.sres[tid] = ofx_cand_none();
-            for (int e = 0; e < 2; ++e) {
+            constexpr int NPASS = SPLIT_EXCHANGE ? 2 : 1;   // SPLIT: even lags, then odd
+            for (int e = 0; e < NPASS; ++e) {
                 __syncthreads();
 #pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1)
-                    L.xb[512 * n1 + tid] = e ? d[n1].y : d[n1].x;   // A(2m+e) at m
+                for (int h = 0; h < VT; ++h)
+#pragma unroll
+                    for (int n1 = 0; n1 < 32; ++n1) {
+                        const int m = 512 * n1 + tid + FT * h;
+                        if constexpr (SPLIT_EXCHANGE) {
+                            L.xb[m] = e ? d[32 * h + n1].y : d[32 * h + n1].x;   // A(2m+e)
+                        } else {
+                            reinterpret_cast<float2*>(L.xb)[m] = d[32 * h + n1]; // A(2m), A(2m+1)
+                        }
+                    }
                 __syncthreads();
                 for (int q = 0; q < sd.n_search; ++q) {
                     const OfxSearchDev& sq = sd.search[q];
@@ -450,7 +551,11 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
                     auto scan = [&](int i0, int i1) {
                         for (int i = i0 + tid; i < i1; i += FT) {
                             const int n = (i - pre) & (FN - 1);
-                            if ((n & 1) == e) ofx_cand_take(c, L.xb[n >> 1], i);
+                            if constexpr (SPLIT_EXCHANGE) {
+                                if ((n & 1) == e) ofx_cand_take(c, L.xb[n >> 1], i);
+                            } else {
+                                ofx_cand_take(c, L.xb[n], i);
+                            }
                         }
                     };
                     if (sq.outside) {
@@ -464,6 +569,13 @@ __global__ __launch_bounds__(FT, 2 * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxS
                 }
             }
             __syncthreads();
+        }
+
+        // d is dead from here on: request the next trace
+        {
+            const long long bn = b + gridDim.x;
+            have = (bn < n_traces) && !(valid && !valid[bn]);
+            if (have) load_trace(bn);
         }
 
         for (int q = 0; q < sd.n_search; ++q) {
@@ -549,9 +661,9 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
     OfxSlotHost& h = p->slot[slot];
     const double PI2 = 6.283185307179586476925286766559;
     const std::vector<double>& g = h.g_host;
-    std::vector<float4> tab(2 * 16 * FT + 1);
+    std::vector<float4> tab(2 * 16 * FV + 1);
     auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
-    for (int v = 0; v < FT; ++v) {
+    for (int v = 0; v < FV; ++v) {
         for (int j = 0; j < 16; ++j) {
             int k;
             if (v != 0) k = v + 1024 * j;
@@ -571,17 +683,17 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
                 gp = g[pidx] / 2.0;
             }
             const double a = -PI2 * (double)k / FN;
-            tab[j * FT + v] = make_float4((float)std::cos(a), (float)std::sin(a),
+            tab[j * FV + v] = make_float4((float)std::cos(a), (float)std::sin(a),
                                           (float)(wkr / 2.0), (float)(wki / 2.0));
-            tab[16 * FT + j * FT + v] =
+            tab[16 * FV + j * FV + v] =
                 make_float4((float)(wpr / 2.0), (float)(-wpi / 2.0), (float)gk, (float)gp);
         }
     }
-    tab[2 * 16 * FT] = make_float4((float)wf[2 * (FM / 2)], (float)wf[2 * (FM / 2) + 1],
+    tab[2 * 16 * FV] = make_float4((float)wf[2 * (FM / 2)], (float)wf[2 * (FM / 2) + 1],
                                    (float)g[FM / 2], 0.0f);
-    h.wq_x = tab[2 * 16 * FT].x;
-    h.wq_y = tab[2 * 16 * FT].y;
-    h.gq = tab[2 * 16 * FT].z;
+    h.wq_x = tab[2 * 16 * FV].x;
+    h.wq_y = tab[2 * 16 * FV].y;
+    h.gq = tab[2 * 16 * FV].z;
     OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
     OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
     return OFX_OK;
@@ -633,7 +745,7 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             tabs.t1 = p->d_tw1;
             tabs.t2 = p->d_tw2;
             tabs.midA = p->slot[s].d_pq;
-            tabs.midB = p->slot[s].d_pq + 16 * FT;
+            tabs.midB = p->slot[s].d_pq + 16 * FV;
             tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
             tabs.gq = p->slot[s].gq;
         } else {
