@@ -469,10 +469,29 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
         }
 #endif
         // ------------------------------------------------------------- tail
+        // max of A^2 per group of 8 register pairs (kept so that the thread holding the
+        // global maximum only has to search one group), then per thread
+        constexpr int NG = NV / 8;
+        float gm[NG];
         float mloc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NV; ++j)
-            mloc = fmaxf(mloc, fmaxf(d[j].x * d[j].x, d[j].y * d[j].y));
+        for (int g = 0; g < NG; ++g) {
+            float m = 0.0f;
+#pragma unroll
+            for (int j = 8 * g; j < 8 * g + 8; ++j)
+                m = fmaxf(m, fmaxf(d[j].x * d[j].x, d[j].y * d[j].y));
+            gm[g] = m;
+            mloc = fmaxf(mloc, m);
+        }
+        // low-frequency chi2 tables for this thread's bins: requested now, used at the end
+        constexpr int NLK = (NLOW_MAX + FT - 1) / FT;
+        float2 lk_s[NLK];
+        float lk_g[NLK];
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            lk_s[i] = sd.s[tid + FT * i];
+            lk_g[i] = sd.g[tid + FT * i];
+        }
         {
             const float wmax = ofx_wave_max(mloc);
             const float wchi = ofx_wave_sum(chi0p);
@@ -506,11 +525,14 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
                 int tb = tid;
                 asm volatile("" : "+v"(tb));   // keep the rolled indices out of LICM
 #pragma unroll
-                for (int h = 0; h < VT; ++h) {
+                for (int g = 0; g < NG; ++g) {
+                    if (__builtin_amdgcn_ballot_w64(gm[g] == Mstar) == 0) continue;   // uniform
+                    const int h = (8 * g) / 32;
                     const int base = 2 * (tb + FT * h) + pre;
 #pragma unroll
-                    for (int n1 = 0; n1 < 32; ++n1) {
-                        const float2 v = d[32 * h + n1];
+                    for (int j = 8 * g; j < 8 * g + 8; ++j) {
+                        const int n1 = j & 31;
+                        const float2 v = d[j];
                         const int i0 = (base + 1024 * n1) & (FN - 1);
                         const int i1 = (base + 1024 * n1 + 1) & (FN - 1);
                         if (v.x * v.x == Mstar && i0 < fullbest.idx) {
@@ -596,10 +618,15 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
             // low-frequency chi2 at (amp, t0)
             const int dl = best.idx - pre;
             float low = 0.0f;
-            for (int k = tid; k < sq.nlow; k += FT) {
-                const float2 x2 = L.xlow[k];
-                low += ofx_lowchi2_term(k, FN, dl, best.amp,
-                                        make_float2(0.5f * x2.x, 0.5f * x2.y), sd.s[k], sd.g[k]);
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) {
+                const int k = tid + FT * i;
+                if (k < sq.nlow) {
+                    const float2 x2 = L.xlow[k];
+                    low += ofx_lowchi2_term(k, FN, dl, best.amp,
+                                            make_float2(0.5f * x2.x, 0.5f * x2.y), lk_s[i],
+                                            lk_g[i]);
+                }
             }
             low = ofx_wave_sum(low);
             __syncthreads();
