@@ -7,8 +7,8 @@
 // z[m] = x[2m] + i x[2m+1]); the whole trace lives in registers, M = 32 x 32 x 16:
 //   m = 512 n1 + 16 n2 + n3      k = k1 + 32 k2 + 1024 k3
 //   F1: virtual thread t = n' = 16 n2 + n3, radix-32 over n1 -> k1, x w_M^{n' k1}
-//   E1: LDS exchange D1[k1][n']            (row stride 513: conflict-free)
-//   F2: virtual thread u = 32 n3 + k1, radix-32 over n2 -> k2, x w_512^{n3 k2}
+//   E1: LDS exchange D1[k1][n']            (row stride 528: conflict-free)
+//   F2: virtual thread u = 16 k1 + n3, radix-32 over n2 -> k2, x w_512^{n3 k2}
 //   E2: LDS exchange D2[k1 + 32 k2][n3]    (row stride 17: conflict-free)
 //   F3: virtual thread v owns the two 16-point blocks k_low = v and its Hermitian
 //       partner 1024 - v (v = 0: the two self-paired blocks 0 and 512), so the
@@ -42,15 +42,20 @@ constexpr int FV = 512;            // virtual threads
 constexpr int FT = FV / VT;        // hardware threads per workgroup
 constexpr int WG_PER_CU = VT;      // workgroups resident per CU
 constexpr int NV = 32 * VT;        // complex values per hardware thread
-constexpr int LD1 = 513;           // D1 row stride (elements)
+constexpr int LD1 = 528;           // D1 row stride (elements); 528 = 16 mod 32
 constexpr int LD2 = 17;            // D2 row stride (elements)
 constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 >= 32*513, >= 16384
 constexpr int NLOW_MAX = 512;
 constexpr int NWAVE = FT / OFX_WAVE;
 
-// With two workgroups per CU, real and imaginary parts go through the exchange
-// buffer separately: 68 KiB per workgroup instead of 136.
+// With two workgroups per CU every exchange runs in two passes through a half-size
+// buffer (68 KiB per workgroup instead of 136): pass 0 moves the rows of the lower
+// half of the layout (D1: k1 < 16, D2: k_low < 512), pass 1 the upper half.  Values
+// stay complex (ds_write_b64 / ds_read_b64: 2/3 of the LDS cycles of a re/im split).
 constexpr bool SPLIT_EXCHANGE = (WG_PER_CU > 1);
+static_assert(!SPLIT_EXCHANGE || VT == 2, "half-buffer exchange assumes VT == 2");
+constexpr int HB1 = 16 * LD1;      // D1 elements per half
+constexpr int HB2 = 512 * LD2;     // D2 elements per half
 
 struct FusedLds {
     float xb[SPLIT_EXCHANGE ? XBUF_ELEMS : 2 * XBUF_ELEMS];   // exchange buffer / lag dump
@@ -228,7 +233,7 @@ struct Roles {
     int vt, n3u, k1u, kB;
     __device__ __forceinline__ explicit Roles(int v) {
         vt = v;
-        n3u = v >> 5; k1u = v & 31;          // F2 / I2 role
+        k1u = v >> 4; n3u = v & 15;          // F2 / I2 role (k1-major)
         kB = partner_block(v);               // F3 / I3 role
     }
     __device__ __forceinline__ int e1w(int k1) const { return k1 * LD1 + vt; }
@@ -259,15 +264,16 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
     const size_t ev_stride = (size_t)pd.n_channels * FN;
     float2 d[NV];
 
-    // LDS exchange of the NV values of a thread; widx / ridx map (role h, value j) to
-    // an element index.  SPLIT: real parts then imaginary parts through the same buffer.
-    auto exchange = [&](auto widx, auto ridx) {
+    // LDS exchange of the NV values of a thread.  widx / ridx map (role h, value j) to
+    // an element index of the full layout; wpass / rpass give the half (0 / 1) that
+    // element belongs to, hb the elements per half.
+    auto exchange = [&](auto widx, auto wpass, auto ridx, auto rpass, int hb) {
 #ifdef ABL_NOEXCH
         return;
 #endif
-        __syncthreads();                       // earlier readers of xb are done
+        float2* xc = reinterpret_cast<float2*>(L.xb);
         if constexpr (!SPLIT_EXCHANGE) {
-            float2* xc = reinterpret_cast<float2*>(L.xb);
+            __syncthreads();                   // earlier readers of xb are done
 #pragma unroll
             for (int h = 0; h < VT; ++h)
 #pragma unroll
@@ -278,25 +284,24 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
 #pragma unroll
                 for (int j = 0; j < 32; ++j) d[32 * h + j] = xc[ridx(h, j)];
         } else {
+            float2 nd[NV];
 #pragma unroll
-            for (int h = 0; h < VT; ++h)
+            for (int p = 0; p < 2; ++p) {
+                __syncthreads();               // earlier readers of xb are done
 #pragma unroll
-                for (int j = 0; j < 32; ++j) L.xb[widx(h, j)] = d[32 * h + j].x;
-            __syncthreads();
+                for (int h = 0; h < VT; ++h)
 #pragma unroll
-            for (int h = 0; h < VT; ++h)
+                    for (int j = 0; j < 32; ++j)
+                        if (wpass(h, j) == p) xc[widx(h, j) - p * hb] = d[32 * h + j];
+                __syncthreads();
 #pragma unroll
-                for (int j = 0; j < 32; ++j) d[32 * h + j].x = L.xb[ridx(h, j)];
-            __syncthreads();
+                for (int h = 0; h < VT; ++h)
 #pragma unroll
-            for (int h = 0; h < VT; ++h)
+                    for (int j = 0; j < 32; ++j)
+                        if (rpass(h, j) == p) nd[32 * h + j] = xc[ridx(h, j) - p * hb];
+            }
 #pragma unroll
-                for (int j = 0; j < 32; ++j) L.xb[widx(h, j)] = d[32 * h + j].y;
-            __syncthreads();
-#pragma unroll
-            for (int h = 0; h < VT; ++h)
-#pragma unroll
-                for (int j = 0; j < 32; ++j) d[32 * h + j].y = L.xb[ridx(h, j)];
+            for (int j = 0; j < NV; ++j) d[j] = nd[j];
         }
     };
 
@@ -404,8 +409,8 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
         if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
         t1_apply<false, 0>(d, t1q, tl);
         if constexpr (VT == 2) t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT);
-        exchange([&](int h, int j) { return RR(h).e1w(j); },
-                 [&](int h, int j) { return RR(h).e1r(j); });
+        exchange([&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; },
+                 [&](int h, int j) { return RR(h).e1r(j); }, [](int h, int) { return h; }, HB1);
         // ---------------------------------------------------------------- F2
         dft<32, -1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
@@ -414,8 +419,9 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
 #pragma unroll
             for (int k2 = 1; k2 < 32; ++k2)
                 d[32 * h + k2] = cmul(d[32 * h + k2], L.t2[k2 * 16 + RR(h).n3u]);
-        exchange([&](int h, int j) { return RR(h).e2w(j); },
-                 [&](int h, int j) { return RR(h).e2r(j); });
+        exchange([&](int h, int j) { return RR(h).e2w(j); }, [](int, int j) { return j >> 4; },
+                 [&](int h, int j) { return RR(h).e2r(j); }, [](int, int j) { return j >> 4; },
+                 HB2);
         // ------------------------------------------- F3, middle, I3 (registers)
         float chi0p = 0.0f;
         {
@@ -440,8 +446,9 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
         asm volatile("" : "+v"(tl2));          // no CSE of addresses across the middle
         const Roles Q0(tl2), Q1(tl2 + FT);
         auto QQ = [&](int h) -> const Roles& { return h == 0 ? Q0 : Q1; };
-        exchange([&](int h, int j) { return QQ(h).e2r(j); },
-                 [&](int h, int j) { return QQ(h).e2w(j); });
+        exchange([&](int h, int j) { return QQ(h).e2r(j); }, [](int, int j) { return j >> 4; },
+                 [&](int h, int j) { return QQ(h).e2w(j); }, [](int, int j) { return j >> 4; },
+                 HB2);
         // ---------------------------------------------------------------- I2
 #pragma unroll
         for (int h = 0; h < VT; ++h)
@@ -450,8 +457,8 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
                 d[32 * h + k2] = cmulc(d[32 * h + k2], L.t2[k2 * 16 + QQ(h).n3u]);
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
-        exchange([&](int h, int j) { return QQ(h).e1r(j); },
-                 [&](int h, int j) { return QQ(h).e1w(j); });
+        exchange([&](int h, int j) { return QQ(h).e1r(j); }, [](int h, int) { return h; },
+                 [&](int h, int j) { return QQ(h).e1w(j); }, [](int, int j) { return j >> 4; }, HB1);
         // ---------------------------------------------------------------- I1
         t1_apply<true, 0>(d, t1q, tl2);
         if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT);
