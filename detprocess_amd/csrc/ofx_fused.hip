@@ -40,7 +40,10 @@ constexpr int FN = 32768;          // samples
 constexpr int FM = 16384;          // packed complex points
 constexpr int FV = 512;            // virtual threads
 constexpr int FT = FV / VT;        // hardware threads per workgroup
-constexpr int WG_PER_CU = VT;      // workgroups resident per CU
+#ifndef OFX_WGPC
+#define OFX_WGPC OFX_VT
+#endif
+constexpr int WG_PER_CU = OFX_WGPC;    // workgroups resident per CU
 constexpr int NV = 32 * VT;        // complex values per hardware thread
 constexpr int LD1 = 528;           // D1 row stride (elements); 528 = 16 mod 32
 constexpr int LD2 = 17;            // D2 row stride (elements)
@@ -53,7 +56,6 @@ constexpr int NWAVE = FT / OFX_WAVE;
 // half of the layout (D1: k1 < 16, D2: k_low < 512), pass 1 the upper half.  Values
 // stay complex (ds_write_b64 / ds_read_b64: 2/3 of the LDS cycles of a re/im split).
 constexpr bool SPLIT_EXCHANGE = (WG_PER_CU > 1);
-static_assert(!SPLIT_EXCHANGE || VT == 2, "half-buffer exchange assumes VT == 2");
 constexpr int HB1 = 16 * LD1;      // D1 elements per half
 constexpr int HB2 = 512 * LD2;     // D2 elements per half
 
@@ -174,27 +176,39 @@ __device__ __forceinline__ float perm_out(float2 (&d)[NV], bool z, float2 a8,
     return chi;
 }
 
-// 16 pair slots; table rows are software-pipelined two slots ahead.
+// 16 pair slots; table rows are software-pipelined MID_DEPTH slots ahead.
+#ifndef OFX_MID_DEPTH
+#define OFX_MID_DEPTH 2
+#endif
+constexpr int MID_DEPTH = OFX_MID_DEPTH;
 template <int O>
 __device__ __forceinline__ float middle_slots(float2 (&d)[NV], __amdgpu_buffer_rsrc_t rmid,
                                               int v, FusedLds& L) {
     // rmid covers [midA: 16 rows][midB: 16 rows], 8 KiB per row
-    float4 ta[3], tb[3];
+    constexpr int NB = MID_DEPTH + 1;
+    float4 ta[NB], tb[NB];
     const int vo = v * 16;
-    ta[0] = buf_ld4(rmid, vo, 0 * 8192);
-    tb[0] = buf_ld4(rmid, vo, (16 + 0) * 8192);
-    ta[1] = buf_ld4(rmid, vo, 1 * 8192);
-    tb[1] = buf_ld4(rmid, vo, (16 + 1) * 8192);
+#pragma unroll
+    for (int j = 0; j < MID_DEPTH; ++j) {
+        ta[j] = buf_ld4(rmid, vo, j * 8192);
+        tb[j] = buf_ld4(rmid, vo, (16 + j) * 8192);
+    }
     float chi = 0.0f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        if (j + 2 < 16) {
-            ta[(j + 2) % 3] = buf_ld4(rmid, vo, (j + 2) * 8192);
-            tb[(j + 2) % 3] = buf_ld4(rmid, vo, (16 + j + 2) * 8192);
+        if (j + MID_DEPTH < 16) {
+            ta[(j + MID_DEPTH) % NB] = buf_ld4(rmid, vo, (j + MID_DEPTH) * 8192);
+            tb[(j + MID_DEPTH) % NB] = buf_ld4(rmid, vo, (16 + j + MID_DEPTH) * 8192);
         }
+#if OFX_MID_DEPTH < 2
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         float2 xk2;
-        chi += mid_slot(d[O + j], d[O + 16 + 15 - j], ta[j % 3], tb[j % 3], xk2);
+        chi += mid_slot(d[O + j], d[O + 16 + 15 - j], ta[j % NB], tb[j % NB], xk2);
         if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
+#if OFX_MID_DEPTH < 2
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     return chi;
 }
@@ -247,7 +261,7 @@ struct Roles {
 // FEAT bit 1: plan has time-domain windows
 // FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
 template <int FEAT>
-__global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
+__global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
                                                  const float* __restrict__ traces,
                                                  const uint8_t* __restrict__ valid,
                                                  long long n_traces, float* __restrict__ out) {
@@ -410,7 +424,7 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
         t1_apply<false, 0>(d, t1q, tl);
         if constexpr (VT == 2) t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT);
         exchange([&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; },
-                 [&](int h, int j) { return RR(h).e1r(j); }, [](int h, int) { return h; }, HB1);
+                 [&](int h, int j) { return RR(h).e1r(j); }, [&](int h, int) { return VT == 2 ? h : (RR(h).k1u >> 4); }, HB1);
         // ---------------------------------------------------------------- F2
         dft<32, -1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
@@ -457,7 +471,7 @@ __global__ __launch_bounds__(FT, 2) void k_fused(OfxPlanDev pd, OfxSlotDev sd, F
                 d[32 * h + k2] = cmulc(d[32 * h + k2], L.t2[k2 * 16 + QQ(h).n3u]);
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
-        exchange([&](int h, int j) { return QQ(h).e1r(j); }, [](int h, int) { return h; },
+        exchange([&](int h, int j) { return QQ(h).e1r(j); }, [&](int h, int) { return VT == 2 ? h : (QQ(h).k1u >> 4); },
                  [&](int h, int j) { return QQ(h).e1w(j); }, [](int, int j) { return j >> 4; }, HB1);
         // ---------------------------------------------------------------- I1
         t1_apply<true, 0>(d, t1q, tl2);
