@@ -215,30 +215,33 @@ __device__ __forceinline__ float middle_slots(float2 (&d)[NV], __amdgpu_buffer_r
 
 // Inter-stage twiddles w_M^{n' k1} (F1: multiply, I1: multiply by the conjugate).
 // t1q[kq][vt] packs (w^{2kq}, w^{2kq+1}); rows are streamed in groups of four.
-template <bool CONJ, int O>
-__device__ __forceinline__ void t1_apply(float2 (&d)[NV], __amdgpu_buffer_rsrc_t t1q, int vt) {
-    float4 cur[4];
+struct T1Group {
+    float4 q[4];
+};
+__device__ __forceinline__ T1Group t1_load(__amdgpu_buffer_rsrc_t t1q, int vt, int g) {
+    T1Group r;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) cur[c] = buf_ld4(t1q, vt * 16, c * 8192);
+    for (int c = 0; c < 4; ++c) r.q[c] = buf_ld4(t1q, vt * 16, (4 * g + c) * 8192);
+    return r;
+}
+// `cur` = group 0, requested by the caller ahead of the preceding DFT / exchange so
+// that its L2 latency is covered; the remaining groups stream one group ahead.
+template <bool CONJ, int O>
+__device__ __forceinline__ void t1_apply(float2 (&d)[NV], __amdgpu_buffer_rsrc_t t1q, int vt,
+                                         T1Group cur) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float4 nxt[4];
-        if (g < 3) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) nxt[c] = buf_ld4(t1q, vt * 16, (4 * (g + 1) + c) * 8192);
-        }
+        T1Group nxt;
+        if (g < 3) nxt = t1_load(t1q, vt, g + 1);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k1 = 8 * g + 2 * c;
-            const float2 w0 = make_float2(cur[c].x, cur[c].y);
-            const float2 w1 = make_float2(cur[c].z, cur[c].w);
+            const float2 w0 = make_float2(cur.q[c].x, cur.q[c].y);
+            const float2 w1 = make_float2(cur.q[c].z, cur.q[c].w);
             if (k1 != 0) d[O + k1] = CONJ ? cmulc(d[O + k1], w0) : cmul(d[O + k1], w0);
             d[O + k1 + 1] = CONJ ? cmulc(d[O + k1 + 1], w1) : cmul(d[O + k1 + 1], w1);
         }
-        if (g < 3) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
-        }
+        if (g < 3) cur = nxt;
     }
 }
 
@@ -419,10 +422,15 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
 
         // ---------------------------------------------------------------- F1
-        dft<32, -1, NV, 0>(d);
-        if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
-        t1_apply<false, 0>(d, t1q, tl);
-        if constexpr (VT == 2) t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT);
+        {
+            const T1Group g0 = t1_load(t1q, tl, 0);
+            const T1Group g1 = t1_load(t1q, tl + FT, 0);
+            __builtin_amdgcn_sched_barrier(0);         // keep the requests ahead of the DFTs
+            dft<32, -1, NV, 0>(d);
+            if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
+            t1_apply<false, 0>(d, t1q, tl, g0);
+            if constexpr (VT == 2) t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT, g1);
+        }
         exchange([&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; },
                  [&](int h, int j) { return RR(h).e1r(j); }, [&](int h, int) { return VT == 2 ? h : (RR(h).k1u >> 4); }, HB1);
         // ---------------------------------------------------------------- F2
@@ -471,11 +479,18 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 d[32 * h + k2] = cmulc(d[32 * h + k2], L.t2[k2 * 16 + QQ(h).n3u]);
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
-        exchange([&](int h, int j) { return QQ(h).e1r(j); }, [&](int h, int) { return VT == 2 ? h : (QQ(h).k1u >> 4); },
-                 [&](int h, int j) { return QQ(h).e1w(j); }, [](int, int j) { return j >> 4; }, HB1);
-        // ---------------------------------------------------------------- I1
-        t1_apply<true, 0>(d, t1q, tl2);
-        if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT);
+        {
+            const T1Group g0 = t1_load(t1q, tl2, 0);
+            const T1Group g1 = t1_load(t1q, tl2 + FT, 0);
+            __builtin_amdgcn_sched_barrier(0);         // requests ahead of the exchange
+            exchange([&](int h, int j) { return QQ(h).e1r(j); },
+                     [&](int h, int) { return VT == 2 ? h : (QQ(h).k1u >> 4); },
+                     [&](int h, int j) { return QQ(h).e1w(j); }, [](int, int j) { return j >> 4; },
+                     HB1);
+            // ------------------------------------------------------------ I1
+            t1_apply<true, 0>(d, t1q, tl2, g0);
+            if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT, g1);
+        }
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
         // d[32 h + n1] = (A(1024 n1 + 2 vt), A(1024 n1 + 2 vt + 1)),  vt = tid + FT h
