@@ -27,6 +27,24 @@ ALGO_BYTES_PER_TRACE = N_SAMPLES * 4 + 16
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md
 
 
+def measured_traffic(engine, traces_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*traffic.json,
+    FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md
+    prescribes); scaled to this run's traces per launch.  None if no matching profile."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("engine") == engine:
+            best = rec
+    if best is None:
+        return None
+    return best["hbm_bytes_per_trace"] * traces_per_launch
+
+
 def cpu_baseline(seconds_target=12.0):
     """The oracle (fp64 NumPy restatement of the detprocess+QETpy per-event path)
     timed on this host, 1 core, on a bounded sample of the same workload."""
@@ -154,7 +172,8 @@ def main():
                        "n_samples": N_SAMPLES, "fs": FS,
                        "parallelism": f"event-range shards x{world}, all-gather of features"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(plan.engine, traces_per_launch),
                          "kernel_ms": k_ms, "launches": k_n,
                          "algorithmic_bytes_per_trace": ALGO_BYTES_PER_TRACE},
         }
