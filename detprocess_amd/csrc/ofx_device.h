@@ -56,9 +56,12 @@ __device__ __forceinline__ OfxCand ofx_cand_wave_reduce(OfxCand c) {
 }
 
 // Block reduce; result valid in every thread.  scratch: >= (nthreads/64) OfxCand.
-__device__ __forceinline__ OfxCand ofx_cand_block_reduce(OfxCand c, OfxCand* scratch) {
-    const int lane = threadIdx.x & (OFX_WAVE - 1);
-    const int wave = threadIdx.x / OFX_WAVE;
+// tid: this thread's index (pass an opaque copy to keep the address arithmetic local).
+__device__ __forceinline__ OfxCand ofx_cand_block_reduce(OfxCand c, OfxCand* scratch,
+                                                         int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
+    const int lane = tid & (OFX_WAVE - 1);
+    const int wave = tid / OFX_WAVE;
     const int nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
     c = ofx_cand_wave_reduce(c);
     __syncthreads();

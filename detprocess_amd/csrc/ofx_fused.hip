@@ -505,6 +505,13 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
 #endif
         // ------------------------------------------------------------- tail
+        // (thread ids of the tail come from an opaque copy: its LDS / table addresses are
+        // recomputed here instead of being hoisted out of the loop and spilled)
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        const int lane_t = tt & 63, wave_t = tt >> 6;
+        const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, NLOW_MAX * 8);
+        const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, NLOW_MAX * 4);
         // max of A^2 per group of 8 register pairs (kept so that the thread holding the
         // global maximum only has to search one group), then per thread
         constexpr int NG = NV / 8;
@@ -525,18 +532,19 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         float lk_g[NLK];
 #pragma unroll
         for (int i = 0; i < NLK; ++i) {
-            lk_s[i] = sd.s[tid + FT * i];
-            lk_g[i] = sd.g[tid + FT * i];
+            lk_s[i] = buf_ld2(rs_s, (tt + FT * i) * 8, 0);
+            lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rs_g, (tt + FT * i) * 4, 0, 0));
         }
         {
             const float wmax = ofx_wave_max(mloc);
             const float wchi = ofx_wave_sum(chi0p);
             __syncthreads();
-            if (lane == 0) {
-                L.red[0][wave] = wmax;
-                L.red[1][wave] = wchi;
+            if (lane_t == 0) {
+                L.red[0][wave_t] = wmax;
+                L.red[1][wave_t] = wchi;
             }
-            if (tid == 0) L.bcast[0] = d[0].x;          // A(lag 0) for nodelay
+            if (tt == 0) L.bcast[0] = d[0].x;          // A(lag 0) for nodelay
             __syncthreads();
         }
         float Mstar = L.red[0][0], chi0 = L.red[1][0];
@@ -558,8 +566,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
         if (any_full) {
             if (mloc == Mstar) {
-                int tb = tid;
-                asm volatile("" : "+v"(tb));   // keep the rolled indices out of LICM
+                const int tb = tt;
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (__builtin_amdgcn_ballot_w64(gm[g] == Mstar) == 0) continue;   // uniform
@@ -580,12 +587,12 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     }
                 }
             }
-            fullbest = ofx_cand_block_reduce(fullbest, L.cand);
+            fullbest = ofx_cand_block_reduce(fullbest, L.cand, tt);
         }
 
         // windowed / outside-window fits scan the lag dump
         if constexpr (FEAT & 1) {
-            if (tid < OFX_MAX_SEARCHES) L.sres[tid] = ofx_cand_none();
+            if (tt < OFX_MAX_SEARCHES) L.sres[tt] = ofx_cand_none();
             constexpr int NPASS = SPLIT_EXCHANGE ? 2 : 1;   // SPLIT: even lags, then odd
             for (int e = 0; e < NPASS; ++e) {
                 __syncthreads();
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 for (int h = 0; h < VT; ++h)
 #pragma unroll
                     for (int n1 = 0; n1 < 32; ++n1) {
-                        const int m = 512 * n1 + tid + FT * h;
+                        const int m = 512 * n1 + tt + FT * h;
                         if constexpr (SPLIT_EXCHANGE) {
                             L.xb[m] = e ? d[32 * h + n1].y : d[32 * h + n1].x;   // A(2m+e)
                         } else {
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     if (sq.kind != OFX_SEARCH_DELAY || full) continue;
                     OfxCand c = ofx_cand_none();
                     auto scan = [&](int i0, int i1) {
-                        for (int i = i0 + tid; i < i1; i += FT) {
+                        for (int i = i0 + tt; i < i1; i += FT) {
                             const int n = (i - pre) & (FN - 1);
                             if constexpr (SPLIT_EXCHANGE) {
                                 if ((n & 1) == e) ofx_cand_take(c, L.xb[n >> 1], i);
@@ -622,8 +629,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     } else {
                         scan(sq.lo, sq.hi);
                     }
-                    c = ofx_cand_block_reduce(c, L.cand);
-                    if (tid == 0 && ofx_cand_better(c.key, c.idx, L.sres[q])) L.sres[q] = c;
+                    c = ofx_cand_block_reduce(c, L.cand, tt);
+                    if (tt == 0 && ofx_cand_better(c.key, c.idx, L.sres[q])) L.sres[q] = c;
                 }
             }
             __syncthreads();
@@ -656,7 +663,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             float low = 0.0f;
 #pragma unroll
             for (int i = 0; i < NLK; ++i) {
-                const int k = tid + FT * i;
+                const int k = tt + FT * i;
                 if (k < sq.nlow) {
                     const float2 x2 = L.xlow[k];
                     low += ofx_lowchi2_term(k, FN, dl, best.amp,
@@ -666,9 +673,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
             low = ofx_wave_sum(low);
             __syncthreads();
-            if (lane == 0) L.red[2][wave] = low;
+            if (lane_t == 0) L.red[2][wave_t] = low;
             __syncthreads();
-            if (tid == 0) {
+            if (tt == 0) {
                 float lw = 0.0f;
                 for (int w = 0; w < NWAVE; ++w) lw += L.red[2][w];
                 ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, lw);
