@@ -64,6 +64,7 @@ struct FusedLds {
     float2 t2[512];                //  4,096 B   w_512^{n3 k2}, index k2*16+n3
     float2 xlow[NLOW_MAX + 8];     //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
+    float tdred[OFX_MAX_TDWIN][3][NWAVE];   // time-domain window partials
     OfxCand cand[NWAVE];
     OfxCand sres[OFX_MAX_SEARCHES];
     float bcast[8];
@@ -373,47 +374,79 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         if (!have) load_trace(b);               // cold start / after an invalid event
 
         // ------------------------------------------------ time-domain windows
+        // Sample index of d[32 h + n1].{x,y} is 1024 n1 + 2 vt + {0,1}: a window [lo, hi)
+        // covers whole rows n1 (uniform test, unmasked adds / max3 / min3), at most two
+        // partial rows (masked), and rows outside it are skipped.
         if constexpr (FEAT & 2) {
+            // end points of the slice owned by thread w (trapezoid correction): requested
+            // first, consumed after the reductions
+            float first = 0.f, last = 0.f;
+            if (tid < pd.n_tdwin) {
+                const int lo = pd.tdw[tid].lo, hi = pd.tdw[tid].hi;
+                const float* e = traces + (size_t)b * ev_stride;
+                if constexpr (FEAT & 4) {
+                    for (int c = 0; c < pd.n_terms; ++c) {
+                        const float* z = e + (size_t)pd.chan[c] * FN;
+                        first = fmaf(pd.weight[c], z[lo], first);
+                        last = fmaf(pd.weight[c], z[hi - 1], last);
+                    }
+                } else {
+                    first = e[lo];
+                    last = e[hi - 1];
+                }
+            }
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-                float s = 0.0f, mx = -INFINITY, mn = INFINITY, fl = 0.0f;
+                float s = 0.0f, mx = -INFINITY, mn = INFINITY;
 #pragma unroll
-                for (int h = 0; h < VT; ++h)
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    const int r0 = 1024 * n1;
+                    if (r0 + 1024 <= lo || r0 >= hi) continue;            // uniform: outside
+                    if (lo <= r0 && r0 + 1024 <= hi) {                    // uniform: full row
 #pragma unroll
-                    for (int n1 = 0; n1 < 32; ++n1) {
-                        const int n = 1024 * n1 + 2 * (tl + FT * h);
-                        const bool in0 = (n >= lo) && (n < hi);
-                        const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
-                        const float x0 = d[32 * h + n1].x, x1 = d[32 * h + n1].y;
-                        s += (in0 ? x0 : 0.0f) + (in1 ? x1 : 0.0f);
-                        mx = fmaxf(mx, fmaxf(in0 ? x0 : -INFINITY, in1 ? x1 : -INFINITY));
-                        mn = fminf(mn, fminf(in0 ? x0 : INFINITY, in1 ? x1 : INFINITY));
-                        if (n == lo || n == hi - 1) fl += x0;
-                        if (n + 1 == lo || n + 1 == hi - 1) fl += x1;
+                        for (int h = 0; h < VT; ++h) {
+                            const float2 v = d[32 * h + n1];
+                            s += v.x + v.y;
+                            mx = fmaxf(mx, fmaxf(v.x, v.y));
+                            mn = fminf(mn, fminf(v.x, v.y));
+                        }
+                    } else {                                              // edge row
+#pragma unroll
+                        for (int h = 0; h < VT; ++h) {
+                            const int n = r0 + 2 * (tl + FT * h);
+                            const bool in0 = (n >= lo) && (n < hi);
+                            const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                            const float2 v = d[32 * h + n1];
+                            s += (in0 ? v.x : 0.0f) + (in1 ? v.y : 0.0f);
+                            mx = fmaxf(mx, fmaxf(in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY));
+                            mn = fminf(mn, fminf(in0 ? v.x : INFINITY, in1 ? v.y : INFINITY));
+                        }
                     }
-                if (hi - lo == 1) fl *= 2.0f;          // first == last sample
+                }
                 s = ofx_wave_sum(s);
                 mx = ofx_wave_max(mx);
                 mn = ofx_wave_min(mn);
-                fl = ofx_wave_sum(fl);
-                __syncthreads();
                 if (lane == 0) {
-                    L.red[0][wave] = s; L.red[1][wave] = mx;
-                    L.red[2][wave] = mn; L.red[3][wave] = fl;
+                    L.tdred[w][0][wave] = s;
+                    L.tdred[w][1][wave] = mx;
+                    L.tdred[w][2][wave] = mn;
                 }
-                __syncthreads();
-                if (tid == 0) {
-                    float S = 0.f, MX = -INFINITY, MN = INFINITY, FLs = 0.f;
-                    for (int q = 0; q < NWAVE; ++q) {
-                        S += L.red[0][q]; MX = fmaxf(MX, L.red[1][q]);
-                        MN = fminf(MN, L.red[2][q]); FLs += L.red[3][q];
-                    }
-                    float* o = row + pd.tdw[w].out_off;
-                    o[OFX_TD_BASELINE] = S / (float)(hi - lo);
-                    o[OFX_TD_INTEGRAL] = (S - 0.5f * FLs) * pd.inv_fs;
-                    o[OFX_TD_MAXIMUM] = MX;
-                    o[OFX_TD_MINIMUM] = MN;
+            }
+            __syncthreads();
+            if (tid < pd.n_tdwin) {                      // one thread finalises one window
+                const int w = tid;
+                const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+                float S = 0.f, MX = -INFINITY, MN = INFINITY;
+                for (int q = 0; q < NWAVE; ++q) {
+                    S += L.tdred[w][0][q];
+                    MX = fmaxf(MX, L.tdred[w][1][q]);
+                    MN = fminf(MN, L.tdred[w][2][q]);
                 }
+                float* o = row + pd.tdw[w].out_off;
+                o[OFX_TD_BASELINE] = S / (float)(hi - lo);
+                o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
+                o[OFX_TD_MAXIMUM] = MX;
+                o[OFX_TD_MINIMUM] = MN;
             }
         }
         if (sd.n_search == 0) {
