@@ -15,11 +15,12 @@ OK = 0
 MEM_HOST, MEM_DEVICE = 0, 1
 ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT = 0, 1, 2
 SEARCH_NODELAY, SEARCH_DELAY = 0, 1
-SEARCH_FLOATS, TDWIN_FLOATS = 8, 4
-MAX_SLOTS, MAX_SEARCHES, MAX_TDWIN, MAX_TERMS = 8, 8, 8, 8
+SEARCH_FLOATS, TDWIN_FLOATS, BAND_FLOATS = 8, 8, 1
+MAX_SLOTS, MAX_SEARCHES, MAX_TDWIN, MAX_TERMS, MAX_BANDS = 8, 8, 8, 8, 16
 COL = {"amp": 0, "t0": 1, "chi2": 2, "lowchi2": 3, "chi2nopulse": 4,
        "ampres": 5, "timeres": 6, "index": 7}
-TD = {"baseline": 0, "integral": 1, "maximum": 2, "minimum": 3}
+TD = {"baseline": 0, "integral": 1, "maximum": 2, "minimum": 3, "sum": 4, "sumsq": 5,
+      "first": 6, "last": 7}
 
 # every symbol include/ofx.h declares: (name, restype, argtypes)
 _p = C.c_void_p
@@ -34,11 +35,13 @@ _SYMBOLS = [
     ("ofx_plan_add_search", C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_double]),
     ("ofx_plan_add_tdwindow", C.c_int, [_p, C.c_int, C.c_int]),
+    ("ofx_plan_add_band", C.c_int, [_p, C.c_int, C.c_int]),
     ("ofx_plan_set_channels", C.c_int, [_p, C.c_int, C.c_int, _p, _p]),
     ("ofx_plan_reset", C.c_int, [_p]),
     ("ofx_plan_row_floats", C.c_int, [_p]),
     ("ofx_plan_search_offset", C.c_int, [_p, C.c_int, C.c_int]),
     ("ofx_plan_tdwindow_offset", C.c_int, [_p, C.c_int]),
+    ("ofx_plan_band_offset", C.c_int, [_p, C.c_int]),
     ("ofx_process", C.c_int, [_p, _p, _p, C.c_longlong, C.c_int, _p, C.c_int, _p]),
     ("ofx_synth_traces", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,

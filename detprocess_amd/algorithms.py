@@ -23,6 +23,47 @@ def _maybe_scalar(arr, squeeze):
 _TD_PLANS = {}
 
 
+def _td_record(trace, fs, windows):
+    """All time-domain records ([B, 8] float64 per window) for a list of slices."""
+    squeeze = False
+    if isinstance(trace, np.ndarray):
+        if trace.ndim == 1:
+            trace, squeeze = trace[np.newaxis, :], True
+        trace = np.ascontiguousarray(trace, dtype=np.float32)
+        device = 0
+    else:
+        if trace.dim() == 1:
+            trace, squeeze = trace[None, :], True
+        device = trace.device.index if trace.is_cuda else 0
+    n = trace.shape[-1]
+    key = (n, float(fs), device)
+    plan = _TD_PLANS.get(key)
+    if plan is None:
+        plan = _TD_PLANS[key] = OFPlan(n, 0, fs, max_batch=4096, device=device)
+    plan.reset()
+    wids = [plan.add_tdwindow(lo, hi) for lo, hi in windows]
+    out = plan.process(trace)
+    if not isinstance(out, np.ndarray):
+        out = out.cpu().numpy()
+    recs = [out[:, plan.tdwindow_offset(w): plan.tdwindow_offset(w) + 8].astype(np.float64)
+            for w in wids]
+    return recs, squeeze
+
+
+def energy_absorbed_value(rec_base, rec_win, n, fs, vb, i0, rl):
+    """energyabsorbed (algorithms.py:938-943) from two GPU window records
+    (baseline window trace[:lo], integration window trace[lo:hi], n = hi - lo):
+    i = x - b; p0 = i (vb - 2 i0 rl) - i^2 rl; trapz(p0)/fs with
+    sum(i) = S - n b and sum(i^2) = Q - 2 b S + n b^2."""
+    b = rec_base[:, 0]
+    S, Q, first, last = rec_win[:, 4], rec_win[:, 5], rec_win[:, 6], rec_win[:, 7]
+    c1 = vb - 2.0 * i0 * rl
+    si = S - n * b
+    si2 = Q - 2.0 * b * S + n * b * b
+    p0 = lambda x: (x - b) * c1 - (x - b) ** 2 * rl
+    return (c1 * si - rl * si2 - 0.5 * (p0(first) + p0(last))) / fs
+
+
 def _td_feature(trace, which, fs, window_min_index, window_max_index):
     """baseline / integral / maximum / minimum of trace[lo:hi] on the GPU."""
     squeeze = False
@@ -99,6 +140,35 @@ class FeatureExtractors:
                         lowchi2_fcutoff)
         sq = of_base.squeeze(channel)
         return {f"{n}_{feature_base_name}": _maybe_scalar(r[n], sq) for n in names}
+
+    @staticmethod
+    def energyabsorbed(trace, fs, vb, i0, rl, window_min_index=None, window_max_index=None,
+                       feature_base_name="energyabsorbed", **kwargs):
+        """algorithms.py:889-949: baseline = mean(trace[:lo]); integral of
+        p0 = i (vb - 2 i0 rl) - i^2 rl over trace[lo:hi] (trapezoid, dx = 1/fs)."""
+        if trace is None or (hasattr(trace, "size") and np.size(trace) == 0):
+            return {feature_base_name: SENTINEL}
+        lo, hi = int(window_min_index), int(window_max_index)
+        if lo < 1:
+            raise ValueError("ERROR: energyabsorbed needs window_min_index >= 1 "
+                             "(the baseline is the mean of trace[:window_min_index])")
+        (rb, rw), squeeze = _td_record(trace, fs, [(0, lo), (lo, hi)])
+        return {feature_base_name: _maybe_scalar(
+            energy_absorbed_value(rb, rw, hi - lo, fs, vb, i0, rl), squeeze)}
+
+    @staticmethod
+    def psd_amp(channel, of_base, f_lims=[], feature_base_name="psd_amp", **kwargs):
+        """algorithms.py:952-1044: average sqrt(folded PSD) of the stored signal in
+        each [f_low, f_high]; keys '<base>_<low>_<high>'."""
+        if not f_lims:
+            raise ValueError('ERROR: "f_lims" required for algorithm psd_amps')
+        from .utils import cleanup_freq_ranges
+        ranges, names = cleanup_freq_ranges(f_lims)
+        if not of_base.is_signal_stored(channel):
+            return {f"{feature_base_name}_{n}": SENTINEL for n in names}
+        vals = of_base.psd_bands(channel, ranges)
+        sq = of_base.squeeze(channel)
+        return {f"{feature_base_name}_{n}": _maybe_scalar(v, sq) for n, v in zip(names, vals)}
 
     @staticmethod
     def baseline(trace, window_min_index=None, window_max_index=None,

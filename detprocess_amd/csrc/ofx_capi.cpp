@@ -32,6 +32,7 @@ int ofx_row_floats(const ofx_plan* p) {
     for (int s = 0; s < OFX_MAX_SLOTS; ++s)
         if (p->slot[s].set) n += (int)p->slot[s].searches.size() * OFX_SEARCH_FLOATS;
     n += (int)p->tdwin.size() * OFX_TDWIN_FLOATS;
+    n += (int)p->bands.size() * OFX_BAND_FLOATS;
     return n;
 }
 
@@ -47,6 +48,10 @@ static void assign_offsets(ofx_plan* p) {
     for (auto& w : p->tdwin) {
         w.out_off = off;
         off += OFX_TDWIN_FLOATS;
+    }
+    for (auto& bd : p->bands) {
+        bd.out_off = off;
+        off += OFX_BAND_FLOATS;
     }
 }
 
@@ -66,6 +71,8 @@ void ofx_fill_plan_dev(const ofx_plan* p, OfxPlanDev* d) {
     }
     d->n_tdwin = (int)p->tdwin.size();
     for (int w = 0; w < d->n_tdwin; ++w) d->tdw[w] = p->tdwin[w];
+    d->n_bands = (int)p->bands.size();
+    for (int i = 0; i < d->n_bands; ++i) d->band[i] = p->bands[i];
 }
 
 void ofx_fill_slot_dev(const ofx_plan* p, int slot, OfxSlotDev* d) {
@@ -129,6 +136,7 @@ extern "C" int ofx_plan_reset(ofx_plan* p) {
     (void)hipSetDevice(p->device);
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) free_slot(p->slot[s]);
     p->tdwin.clear();
+    p->bands.clear();
     p->n_channels = 1;
     p->n_terms = 1;
     p->chan[0] = 0;
@@ -275,6 +283,26 @@ extern "C" int ofx_plan_add_tdwindow(ofx_plan* p, int lo, int hi) {
     return (int)p->tdwin.size() - 1;
 }
 
+extern "C" int ofx_plan_add_band(ofx_plan* p, int k_lo, int k_hi) {
+    if (!p) return -OFX_ERR_ARG;
+    if ((int)p->bands.size() >= OFX_MAX_BANDS) {
+        ofx_set_error("ofx_plan_add_band: more than %d bands", OFX_MAX_BANDS);
+        return -OFX_ERR_ARG;
+    }
+    if (k_lo < 1 || k_hi <= k_lo || k_hi > p->K || (p->N & 1)) {
+        ofx_set_error("ofx_plan_add_band: need 1 <= k_lo=%d < k_hi=%d <= %d (even trace "
+                      "length)", k_lo, k_hi, p->K);
+        return -OFX_ERR_ARG;
+    }
+    OfxBandDev bd;
+    bd.k_lo = k_lo;
+    bd.k_hi = k_hi;
+    bd.out_off = 0;
+    p->bands.push_back(bd);
+    assign_offsets(p);
+    return (int)p->bands.size() - 1;
+}
+
 extern "C" int ofx_plan_set_channels(ofx_plan* p, int n_channels, int n_terms,
                                      const int* chan_index, const double* weight) {
     if (!p || n_channels < 1 || n_terms < 1 || n_terms > OFX_MAX_TERMS || !chan_index) {
@@ -309,6 +337,11 @@ extern "C" int ofx_plan_search_offset(const ofx_plan* p, int slot, int search) {
 extern "C" int ofx_plan_tdwindow_offset(const ofx_plan* p, int w) {
     if (!p || w < 0 || w >= (int)p->tdwin.size()) return -1;
     return p->tdwin[w].out_off;
+}
+
+extern "C" int ofx_plan_band_offset(const ofx_plan* p, int i) {
+    if (!p || i < 0 || i >= (int)p->bands.size()) return -1;
+    return p->bands[i].out_off;
 }
 
 // ------------------------------------------------------------------- timing
@@ -375,7 +408,7 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
     }
     const int row = ofx_row_floats(p);
     if (row == 0) {
-        ofx_set_error("ofx_process: plan has no searches and no time-domain windows");
+        ofx_set_error("ofx_process: plan has no searches, time-domain windows or bands");
         return OFX_ERR_STATE;
     }
     if (n == 0) return OFX_OK;

@@ -61,6 +61,11 @@ struct OfxTdWinDev {
     int out_off;
 };
 
+struct OfxBandDev {
+    int k_lo, k_hi;     // one-sided bins [k_lo, k_hi)
+    int out_off;
+};
+
 struct OfxPlanDev {
     int N, K, pre;
     float fs, inv_fs;
@@ -70,6 +75,8 @@ struct OfxPlanDev {
     float weight[OFX_MAX_TERMS];
     int n_tdwin;
     OfxTdWinDev tdw[OFX_MAX_TDWIN];
+    int n_bands;
+    OfxBandDev band[OFX_MAX_BANDS];
 };
 
 // ------------------------------------------------------------------ host plan
@@ -103,6 +110,7 @@ struct ofx_plan {
     double weight[OFX_MAX_TERMS] = {1.0};
     OfxSlotHost slot[OFX_MAX_SLOTS];
     std::vector<OfxTdWinDev> tdwin;
+    std::vector<OfxBandDev> bands;
     int cu_count = 256;
 
     // ROCFFT engine buffers (lazy)

@@ -64,7 +64,7 @@ struct FusedLds {
     float2 t2[512];                //  4,096 B   w_512^{n3 k2}, index k2*16+n3
     float2 xlow[NLOW_MAX + 8];     //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
-    float tdred[OFX_MAX_TDWIN][3][NWAVE];   // time-domain window partials
+    float tdred[OFX_MAX_TDWIN][4][NWAVE];   // time-domain window partials
     OfxCand cand[NWAVE];
     OfxCand sres[OFX_MAX_SEARCHES];
     float bcast[8];
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-                float s = 0.0f, mx = -INFINITY, mn = INFINITY;
+                float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
                     const int r0 = 1024 * n1;
@@ -407,6 +407,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         for (int h = 0; h < VT; ++h) {
                             const float2 v = d[32 * h + n1];
                             s += v.x + v.y;
+                            sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
                             mx = fmaxf(mx, fmaxf(v.x, v.y));
                             mn = fminf(mn, fminf(v.x, v.y));
                         }
@@ -417,36 +418,45 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                             const bool in0 = (n >= lo) && (n < hi);
                             const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
                             const float2 v = d[32 * h + n1];
-                            s += (in0 ? v.x : 0.0f) + (in1 ? v.y : 0.0f);
+                            const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
+                            s += y0 + y1;
+                            sq = fmaf(y0, y0, fmaf(y1, y1, sq));
                             mx = fmaxf(mx, fmaxf(in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY));
                             mn = fminf(mn, fminf(in0 ? v.x : INFINITY, in1 ? v.y : INFINITY));
                         }
                     }
                 }
                 s = ofx_wave_sum(s);
+                sq = ofx_wave_sum(sq);
                 mx = ofx_wave_max(mx);
                 mn = ofx_wave_min(mn);
                 if (lane == 0) {
                     L.tdred[w][0][wave] = s;
                     L.tdred[w][1][wave] = mx;
                     L.tdred[w][2][wave] = mn;
+                    L.tdred[w][3][wave] = sq;
                 }
             }
             __syncthreads();
             if (tid < pd.n_tdwin) {                      // one thread finalises one window
                 const int w = tid;
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-                float S = 0.f, MX = -INFINITY, MN = INFINITY;
+                float S = 0.f, SQ = 0.f, MX = -INFINITY, MN = INFINITY;
                 for (int q = 0; q < NWAVE; ++q) {
                     S += L.tdred[w][0][q];
                     MX = fmaxf(MX, L.tdred[w][1][q]);
                     MN = fminf(MN, L.tdred[w][2][q]);
+                    SQ += L.tdred[w][3][q];
                 }
                 float* o = row + pd.tdw[w].out_off;
                 o[OFX_TD_BASELINE] = S / (float)(hi - lo);
                 o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
                 o[OFX_TD_MAXIMUM] = MX;
                 o[OFX_TD_MINIMUM] = MN;
+                o[OFX_TD_SUM] = S;
+                o[OFX_TD_SUMSQ] = SQ;
+                o[OFX_TD_FIRST] = first;
+                o[OFX_TD_LAST] = last;
             }
         }
         if (sd.n_search == 0) {
@@ -669,6 +679,21 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             __syncthreads();
         }
 
+        // psd_amp bands from the stashed 2 X_k (k < NLOW_MAX); one wave per band
+        if (pd.n_bands > 0) {
+            const float cpsd = 0.25f / ((float)FN * pd.fs);      // (2 X)^2 / 4 / (N fs)
+            for (int i = wave_t; i < pd.n_bands; i += NWAVE) {
+                const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
+                float acc = 0.0f;
+                for (int k = lo + lane_t; k < hi; k += 64) {
+                    const float2 x2 = L.xlow[k];
+                    acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
+                }
+                acc = ofx_wave_sum(acc);
+                if (lane_t == 0) row[pd.band[i].out_off] = acc / (float)(hi - lo);
+            }
+        }
+
         // d is dead from here on: request the next trace
         {
             const long long bn = b + gridDim.x;
@@ -857,9 +882,25 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             tabs.t1 = p->d_tw1;
             tabs.t2 = p->d_tw2;
         }
-        // time-domain windows ride on the first launch only
+        // time-domain windows and bands ride on the first launch only
         OfxPlanDev pdl = pd;
-        if (!first) pdl.n_tdwin = 0;
+        if (!first) {
+            pdl.n_tdwin = 0;
+            pdl.n_bands = 0;
+        }
+        if (pdl.n_bands > 0) {
+            if (nslots == 0) {
+                ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
+                              "search on the plan (use the ROCFFT engine otherwise)");
+                return OFX_ERR_UNSUPPORTED;
+            }
+            for (int i = 0; i < pdl.n_bands; ++i)
+                if (pdl.band[i].k_hi > NLOW_MAX) {
+                    ofx_set_error("FUSED engine: band [%d,%d) exceeds the %d stashed bins",
+                                  pdl.band[i].k_lo, pdl.band[i].k_hi, NLOW_MAX);
+                    return OFX_ERR_UNSUPPORTED;
+                }
+        }
         int feat = 0;
         for (int q = 0; q < sd.n_search; ++q) {
             const OfxSearchDev& sq = sd.search[q];

@@ -39,14 +39,16 @@ __global__ __launch_bounds__(RB) void k_prep(OfxPlanDev pd, const float* __restr
 
     for (int w = 0; w < pd.n_tdwin; ++w) {
         const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-        float s = 0.0f, mx = -INFINITY, mn = INFINITY;
+        float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
         for (int n = lo + threadIdx.x; n < hi; n += RB) {
             const float v = sample(n);
             s += v;
+            sq = fmaf(v, v, sq);
             mx = fmaxf(mx, v);
             mn = fminf(mn, v);
         }
         s = ofx_block_sum(s, scratch);
+        sq = ofx_block_sum(sq, scratch);
         mx = ofx_block_max(mx, scratch);
         mn = ofx_block_min(mn, scratch);
         if (threadIdx.x == 0) {
@@ -56,7 +58,40 @@ __global__ __launch_bounds__(RB) void k_prep(OfxPlanDev pd, const float* __restr
             o[OFX_TD_INTEGRAL] = (s - 0.5f * (first + last)) * pd.inv_fs;
             o[OFX_TD_MAXIMUM] = mx;
             o[OFX_TD_MINIMUM] = mn;
+            o[OFX_TD_SUM] = s;
+            o[OFX_TD_SUMSQ] = sq;
+            o[OFX_TD_FIRST] = first;
+            o[OFX_TD_LAST] = last;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// psd_amp bands: mean over bins [k_lo, k_hi) of sqrt(w_k |V_k|^2 / (N fs))
+// (algorithms.py:1013-1038).  One block per trace.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(RB) void k_bands(OfxPlanDev pd, const float2* __restrict__ spec,
+                                              const uint8_t* __restrict__ valid,
+                                              float* __restrict__ out) {
+    __shared__ float scratch[RB / OFX_WAVE];
+    const size_t b = blockIdx.x;
+    float* row = out + b * pd.row;
+    if (valid && !valid[b]) {
+        for (int i = threadIdx.x; i < pd.n_bands; i += RB) row[pd.band[i].out_off] = OFX_SENTINEL;
+        return;
+    }
+    const float2* V = spec + b * pd.K;
+    const float c = 1.0f / ((float)pd.N * pd.fs);
+    for (int i = 0; i < pd.n_bands; ++i) {
+        const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
+        float acc = 0.0f;
+        for (int k = lo + threadIdx.x; k < hi; k += RB) {
+            const float2 v = V[k];
+            const float w = (2 * k == pd.N) ? 1.0f : 2.0f;
+            acc += sqrtf(w * c * (v.x * v.x + v.y * v.y));
+        }
+        acc = ofx_block_sum(acc, scratch);
+        if (threadIdx.x == 0) row[pd.band[i].out_off] = acc / (float)(hi - lo);
     }
 }
 
@@ -198,7 +233,7 @@ int ofx_rocfft_release(ofx_plan* p) {
 int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                        long long n, float* d_out, hipStream_t st) {
     const int N = p->N, K = p->K, MB = p->max_batch;
-    bool any_slot = false;
+    bool any_slot = !p->bands.empty();       // bands need the forward FFT too
     for (int s = 0; s < OFX_MAX_SLOTS; ++s)
         if (p->slot[s].set && !p->slot[s].searches.empty()) any_slot = true;
     const bool need_combine = p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0;
@@ -237,6 +272,8 @@ int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_vali
         rc = ofx_time_begin(p, st, &tix);
         if (rc) return rc;
         OFX_FFT(rocfft_execute(f->r2c, in1, out1, f->info_r2c));
+        if (!p->bands.empty())
+            hipLaunchKernelGGL(k_bands, dim3(nb), dim3(RB), 0, st, pd, p->d_spec, vld, out);
         for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
             if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
             OfxSlotDev sd;

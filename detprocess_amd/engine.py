@@ -77,6 +77,13 @@ class OFPlan:
             _lib.check(-wid, "ofx_plan_add_tdwindow")
         return wid
 
+    def add_band(self, k_lo, k_hi):
+        """psd_amp band over one-sided FFT bins [k_lo, k_hi)."""
+        bid = self._lib.ofx_plan_add_band(self._h, int(k_lo), int(k_hi))
+        if bid < 0:
+            _lib.check(-bid, "ofx_plan_add_band")
+        return bid
+
     def set_channels(self, n_channels, chan_index, weights=None):
         idx = np.ascontiguousarray(chan_index, dtype=np.int32)
         w = np.ones(len(idx)) if weights is None else np.ascontiguousarray(
@@ -100,6 +107,9 @@ class OFPlan:
 
     def tdwindow_offset(self, window):
         return self._lib.ofx_plan_tdwindow_offset(self._h, int(window))
+
+    def band_offset(self, band):
+        return self._lib.ofx_plan_band_offset(self._h, int(band))
 
     # ----------------------------------------------------------------- timing
     def enable_timing(self, on=True):

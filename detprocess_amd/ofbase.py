@@ -236,5 +236,25 @@ class OFBase:
         self._fit_cache[ck] = res
         return res
 
+    def psd_bands(self, channel, freq_ranges):
+        """psd_amp: mean sqrt(folded PSD) of the stored batch per frequency range
+        (algorithms.py:1001-1044); returns a list of float32 arrays [B]."""
+        from .utils import get_bin_ranges
+        if not self.is_signal_stored(channel):
+            raise ValueError(f"ERROR: no signal stored for channel {channel}")
+        sig = self._signals[channel]
+        n = sig.shape[-1]
+        key = ("bands", n)
+        if key not in self._plans:
+            self._plans[key] = OFPlan(n, 0, self._fs, max_batch=self._max_batch,
+                                      device=self._device, engine="rocfft")
+        plan = self._plans[key]
+        plan.reset()
+        ids = [plan.add_band(lo, hi) for lo, hi in get_bin_ranges(freq_ranges, n, self._fs)]
+        out = plan.process(sig)
+        if not isinstance(out, np.ndarray):
+            out = out.cpu().numpy()
+        return [out[:, plan.band_offset(i)] for i in ids]
+
     def squeeze(self, channel):
         return self._squeeze.get(channel, False)

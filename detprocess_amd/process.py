@@ -29,6 +29,7 @@ OF_ALGORITHMS = {
                                     "ampres", "timeres")),
 }
 TD_ALGORITHMS = ("baseline", "integral", "maximum", "minimum")
+FUSED_MAX_BAND_BIN = 512       # bins the FUSED engine keeps for psd_amp / lowchi2
 # algorithms whose base name contains one of these get an OFBase in the reference
 # (processing_data.py:93-97); the ones not implemented here raise explicitly
 OF_BASE_PREFIXES = ["of1x1", "of1x2x2", "of1x3x3", "ofnxm", "ofnxmx2", "psd_amp",
@@ -39,6 +40,7 @@ class _ChannelPlan:
     def __init__(self):
         self.plan = None
         self.columns = []       # (column name, row offset)
+        self.energy = []        # (column name, base window off, window off, n, vb, i0, rl)
 
 
 class FeatureProcessing:
@@ -133,7 +135,17 @@ class FeatureProcessing:
                     pending.append(("of", algorithm, base, skey, params, wmin, wmax, npre))
                 elif base in TD_ALGORITHMS:
                     pending.append(("td", algorithm, base, None, params, wmin, wmax, npre))
-                elif any(p in base for p in OF_BASE_PREFIXES) or base == "energyabsorbed":
+                elif base == "energyabsorbed":
+                    for key in ("vb", "i0", "rl"):
+                        if key not in params:
+                            raise ValueError(f'ERROR: energyabsorbed requires "{key}" '
+                                             f"(channel {channel})")
+                    pending.append(("energy", algorithm, base, None, params, wmin, wmax, npre))
+                elif base == "psd_amp":
+                    if not params.get("f_lims"):
+                        raise ValueError('ERROR: "f_lims" required for algorithm psd_amps')
+                    pending.append(("band", algorithm, base, None, params, wmin, wmax, npre))
+                elif any(p in base for p in OF_BASE_PREFIXES):
                     raise NotImplementedError(
                         f'algorithm "{base}" is outside the of1x1 hot path of this engine')
                 else:
@@ -141,8 +153,21 @@ class FeatureProcessing:
                                      f"Check feature extractor exists!")
             if not pending:
                 continue
+            # psd_amp bands ride on a filter slot in the FUSED engine (and only the
+            # lowest bins); otherwise the general ROCFFT engine carries them
+            engine = self._engine
+            bands = [x for x in pending if x[0] == "band"]
+            if bands and engine != "rocfft":
+                has_of = any(x[0] == "of" for x in pending)
+                kmax = 0
+                for x in bands:
+                    rng, _ = utils.cleanup_freq_ranges(x[4]["f_lims"])
+                    kmax = max([kmax] + [hi for _, hi in utils.get_bin_ranges(rng, n_samples,
+                                                                              self._fs)])
+                if not has_of or kmax > FUSED_MAX_BAND_BIN:
+                    engine = "rocfft"
             plan = OFPlan(n_samples, nb_pre_plan, self._fs, max_batch=self._max_batch,
-                          device=self._device, engine=self._engine)
+                          device=self._device, engine=engine)
             if len(self._channels) > 1 or len(idx) > 1 or w[0] != 1.0:
                 plan.set_channels(len(self._channels), idx, w)
             cols = []
@@ -192,6 +217,20 @@ class FeatureProcessing:
                     else:
                         sid = plan.add_search(slot, skind, lowchi2_fcutoff=fcut)
                     cols.append(("of", slot, sid, qtys, algorithm))
+                elif kind == "band":
+                    rng, rnames = utils.cleanup_freq_ranges(params["f_lims"])
+                    for (klo, khi), rname in zip(utils.get_bin_ranges(rng, n_samples, self._fs),
+                                                 rnames):
+                        cols.append(("band", plan.add_band(klo, khi), f"{algorithm}_{rname}"))
+                elif kind == "energy":
+                    if wmin < 1:
+                        raise ValueError("ERROR: energyabsorbed needs a window starting after "
+                                         "sample 0 (its baseline is mean(trace[:window_min]))")
+                    for key in ((0, wmin), (wmin, wmax)):
+                        if key not in td_windows:
+                            td_windows[key] = plan.add_tdwindow(*key)
+                    cols.append(("energy", td_windows[(0, wmin)], td_windows[(wmin, wmax)],
+                                 wmax - wmin, params, algorithm))
                 else:
                     hi = wmax              # end-exclusive slice trace[wmin:wmax]
                     key = (wmin, hi)
@@ -205,6 +244,13 @@ class FeatureProcessing:
                     for q in qtys:
                         cp.columns.append((f"{q}_{algorithm}_{feature_channel}",
                                            off + _lib.COL[q]))
+                elif c[0] == "band":
+                    cp.columns.append((f"{c[2]}_{feature_channel}", plan.band_offset(c[1])))
+                elif c[0] == "energy":
+                    _, wb, ww, nwin, params, algorithm = c
+                    cp.energy.append((f"{algorithm}_{feature_channel}", plan.tdwindow_offset(wb),
+                                      plan.tdwindow_offset(ww), nwin, float(params["vb"]),
+                                      float(params["i0"]), float(params["rl"])))
                 else:
                     _, wid, base, algorithm = c
                     off = plan.tdwindow_offset(wid)
@@ -216,7 +262,8 @@ class FeatureProcessing:
 
     # ----------------------------------------------------------------- process
     def columns(self):
-        return [name for cp in (self._plans or {}).values() for name, _ in cp.columns]
+        return [name for cp in (self._plans or {}).values()
+                for name in [c[0] for c in cp.columns] + [e[0] for e in cp.energy]]
 
     def process(self, traces, valid=None, as_dataframe=True):
         """traces: float32 [B, C, N] (C = len(available_channels)) or [B, N] when there
@@ -243,6 +290,13 @@ class FeatureProcessing:
                 out = out.cpu().numpy()
             for name, off in cp.columns:
                 result[name] = out[:, off].astype(np.float64)
+            for name, ob, ow, nwin, vb, i0, rl in cp.energy:
+                from .algorithms import energy_absorbed_value
+                o64 = out.astype(np.float64)
+                val = energy_absorbed_value(o64[:, ob:ob + 8], o64[:, ow:ow + 8], nwin,
+                                            self._fs, vb, i0, rl)
+                bad = out[:, ow] == -999999.0
+                result[name] = np.where(bad, -999999.0, val)
         if as_dataframe:
             import pandas as pd
             return pd.DataFrame(result)

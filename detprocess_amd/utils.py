@@ -109,3 +109,53 @@ def get_window_indices(nb_samples, nb_pretrigger_samples, fs,
 
 
 extract_window_indices = get_window_indices
+
+
+def cleanup_freq_ranges(f_lims):
+    """Normalise ``f_lims`` (psd_amp) into [[f_low, f_high], ...] + range names
+    '<low>_<high>' (rounded) -- detprocess/utils/utils.py:437-470."""
+    if not isinstance(f_lims, list):
+        f_lims = [f_lims]
+    ranges, names = [], []
+    for fr in f_lims:
+        if isinstance(fr, (int, float)):
+            fr = [fr]
+        f_low = abs(fr[0])
+        if len(fr) == 2:
+            f_high = abs(fr[1])
+            if f_low > f_high:
+                f_low, f_high = f_high, f_low
+            name = f"{round(f_low)}_{round(f_high)}"
+            rng = [f_low, f_high]
+        else:
+            name = f"{round(f_low)}"
+            rng = [f_low]
+        if name not in names:
+            ranges.append(rng)
+            names.append(name)
+    return ranges, names
+
+
+def get_bin_ranges(freq_ranges, nb_samples, fs):
+    """One-sided FFT bin ranges [k_lo, k_hi) of psd_amp: the reference indexes the
+    DC-dropped folded spectrum (detprocess/utils/utils.py:475-504 applied to
+    freqs_fold[1:], algorithms.py:1018-1024), so index i is bin k = i + 1."""
+    import numpy as np
+    freqs = np.fft.rfftfreq(nb_samples, d=1.0 / fs)[1:]
+    out = []
+    for fr in freq_ranges:
+        lo = int(np.argmin(np.abs(freqs - abs(fr[0]))))
+        hi = lo + 1
+        if len(fr) == 2:
+            hi = int(np.argmin(np.abs(freqs - abs(fr[1]))))
+        if lo > hi:
+            lo, hi = hi, lo
+        if lo == hi:
+            if hi < len(freqs) - 1:
+                hi += 1
+            elif lo > 0:
+                lo -= 1
+            else:
+                raise ValueError("Frequency range too narrow or outside bounds.")
+        out.append((lo + 1, hi + 1))
+    return out

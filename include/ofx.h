@@ -49,6 +49,7 @@ enum {
 #define OFX_MAX_SLOTS 8       /* (template_tag, csd_tag) filters per plan     */
 #define OFX_MAX_SEARCHES 8    /* of1x1 algorithm instances per filter slot    */
 #define OFX_MAX_TDWIN 8       /* baseline/integral/min/max windows per plan   */
+#define OFX_MAX_BANDS 16      /* psd_amp frequency bands per plan             */
 #define OFX_MAX_TERMS 8       /* channels combined by '+' / '-' on load       */
 
 /* per-search output record, floats, in this order */
@@ -64,13 +65,20 @@ enum {
     OFX_COL_INDEX = 7         /* rolled bin index of the fit, as a float      */
 };
 /* per-time-domain-window output record, floats, in this order */
-#define OFX_TDWIN_FLOATS 4
+#define OFX_TDWIN_FLOATS 8
 enum {
     OFX_TD_BASELINE = 0,      /* algorithms.py:698  mean(trace[lo:hi])        */
     OFX_TD_INTEGRAL = 1,      /* algorithms.py:759  trapz(trace[lo:hi])/fs    */
     OFX_TD_MAXIMUM = 2,       /* algorithms.py:818                            */
-    OFX_TD_MINIMUM = 3        /* algorithms.py:879                            */
+    OFX_TD_MINIMUM = 3,       /* algorithms.py:879                            */
+    OFX_TD_SUM = 4,           /* sum(trace[lo:hi])      } inputs of           */
+    OFX_TD_SUMSQ = 5,         /* sum(trace[lo:hi]**2)   } energyabsorbed,     */
+    OFX_TD_FIRST = 6,         /* trace[lo]              } algorithms.py:938-943 */
+    OFX_TD_LAST = 7           /* trace[hi-1]            }                     */
 };
+/* per-band output: ONE float = mean over bins [k_lo, k_hi) of
+ * sqrt(folded PSD of the event) -- psd_amp, algorithms.py:1013-1038 */
+#define OFX_BAND_FLOATS 1
 
 /* last error text of the calling thread ("" if none). */
 const char* ofx_last_error(void);
@@ -125,6 +133,14 @@ int ofx_plan_add_search(ofx_plan* plan, int slot, int kind, int lo, int hi,
 int ofx_plan_add_tdwindow(ofx_plan* plan, int lo, int hi);
 
 /*
+ * Register one psd_amp band: one-sided FFT bins [k_lo, k_hi), 1 <= k_lo < k_hi <=
+ * n/2+1 (bin 0 = DC is dropped by the reference, algorithms.py:1018-1021).  The
+ * feature is mean_k sqrt(w_k |V_k|^2 / (N fs)), w_k = 2 (1 at Nyquist): the folded
+ * PSD of algorithms.py:1013-1016.  Returns the band id (>= 0) or a negative error.
+ */
+int ofx_plan_add_band(ofx_plan* plan, int k_lo, int k_hi);
+
+/*
  * Channel algebra on load: the processed trace is sum_j weight[j] *
  * event[chan_index[j]] over the n_channels rows of each event.  Replaces
  * ProcessingData.get_channel_trace -- processing_data.py:1033-1047.
@@ -137,10 +153,12 @@ int ofx_plan_set_channels(ofx_plan* plan, int n_channels, int n_terms,
 int ofx_plan_reset(ofx_plan* plan);
 
 /* floats per output row:  sum over slots of n_search*OFX_SEARCH_FLOATS,
- * then n_tdwin*OFX_TDWIN_FLOATS.  Column offsets via the two calls below. */
+ * then n_tdwin*OFX_TDWIN_FLOATS, then n_bands*OFX_BAND_FLOATS.  Column offsets
+ * via the calls below. */
 int ofx_plan_row_floats(const ofx_plan* plan);
 int ofx_plan_search_offset(const ofx_plan* plan, int slot, int search);
 int ofx_plan_tdwindow_offset(const ofx_plan* plan, int window);
+int ofx_plan_band_offset(const ofx_plan* plan, int band);
 
 /*
  * Process n_traces events.  traces: float32 [n_traces, n_channels, n_samples],

@@ -317,6 +317,75 @@ def energyabsorbed(trace, fs, vb, i0, rl, window_min_index, window_max_index):
     return (np.sum(p0, axis=-1) - 0.5 * (p0[..., 0] + p0[..., -1])) / fs
 
 
+def cleanup_freq_ranges(f_lims):
+    """utils/utils.py:437-470: normalised [f_low, f_high] list + range names."""
+    if not isinstance(f_lims, list):
+        f_lims = [f_lims]
+    ranges, names = [], []
+    for fr in f_lims:
+        if isinstance(fr, (int, float)):
+            fr = [fr]
+        f_low = abs(fr[0])
+        if len(fr) == 2:
+            f_high = abs(fr[1])
+            if f_low > f_high:
+                f_low, f_high = f_high, f_low
+            name = f"{round(f_low)}_{round(f_high)}"
+            if name not in names:
+                ranges.append([f_low, f_high])
+                names.append(name)
+        else:
+            name = f"{round(f_low)}"
+            if name not in names:
+                ranges.append([f_low])
+                names.append(name)
+    return ranges, names
+
+
+def get_ind_freq_ranges(freq_ranges, freqs):
+    """utils/utils.py:475-504 (indices into the DC-dropped folded arrays)."""
+    out = []
+    for fr in freq_ranges:
+        lo = int(np.argmin(np.abs(freqs - abs(fr[0]))))
+        hi = lo + 1
+        if len(fr) == 2:
+            hi = int(np.argmin(np.abs(freqs - abs(fr[1]))))
+        if lo > hi:
+            lo, hi = hi, lo
+        if lo == hi:
+            if hi < len(freqs) - 1:
+                hi += 1
+            elif lo > 0:
+                lo -= 1
+            else:
+                raise ValueError("Frequency range too narrow or outside bounds.")
+        out.append([lo, hi])
+    return out
+
+
+def psd_amp(trace, fs, f_lims):
+    """algorithms.py:1001-1044: psd = |FFT/N|^2 N/fs, folded (x2 except DC and
+    Nyquist), DC dropped, sqrt, averaged over [ind_low, ind_high)."""
+    x = np.asarray(trace, dtype=np.float64)
+    n = x.shape[-1]
+    V = np.fft.fft(x, axis=-1) / n
+    psd = np.abs(V) ** 2 * n / fs
+    k = n // 2 + 1
+    fold = psd[..., :k].copy()
+    if n % 2:
+        fold[..., 1:] *= 2.0
+    else:
+        fold[..., 1:-1] *= 2.0
+    freqs = np.fft.rfftfreq(n, d=1.0 / fs)
+    amp = np.sqrt(fold[..., 1:])
+    ff = freqs[1:]
+    ranges, names = cleanup_freq_ranges(f_lims)
+    res = {}
+    for (lo, hi), name in zip(get_ind_freq_ranges(ranges, ff), names):
+        res[name] = np.average(amp[..., lo:hi], axis=-1)
+    return res
+
+
 # ----------------------------------------------------------------------------
 # window helper: features.py:1243-1344 (twin at utils/utils.py:189-301)
 # ----------------------------------------------------------------------------

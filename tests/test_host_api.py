@@ -297,3 +297,78 @@ def test_feature_processing_batch_driver(engine):
                        atol=2e-4 * filt.ampres)
     assert np.allclose(df["integral_MelangeSum"][ok], orc.integral(xs, FS, 0, n - 1)[ok],
                        rtol=1e-4, atol=1e-6 * np.abs(xs).max() * n / FS)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+def test_psd_amp_and_energyabsorbed(engine):
+    """psd_amp (algorithms.py:952-1044) and
+    energyabsorbed (:889-949) reuse data the kernel already holds."""
+    import torch
+    from detprocess_amd import FeatureExtractors as FE, FeatureProcessing, OFBase, OFPlan, build_filter
+    from oracle import of1x1 as orc
+    n, pre = 32768, 16384
+    fd, J = _filter_data(n, pre)
+    tmpl = synth.make_template(n, pre, FS)
+    ft = build_filter(tmpl, J, FS, pre)
+    x, _, _ = synth.make_traces(7, tmpl, J, FS, ft.ampres, seed=77)
+    x32 = (x + 2.5e-7).astype(np.float32)          # DC offset like a real TES current
+    x64 = x32.astype(np.float64)
+    f_lims = [[45.0, 75.0], [300.0, 500.0], [350.0, 450.0], [150, 250], [3000, 9000], 120.0]
+    want = orc.psd_amp(x64, FS, f_lims)
+    # C ABI level
+    plan = OFPlan(n, pre, FS, max_batch=4, device=0, engine=engine)
+    plan.set_filter(0, ft)
+    plan.add_search(0, "nodelay")
+    rng, names = utils.cleanup_freq_ranges(f_lims)
+    ids = [plan.add_band(lo, hi) for lo, hi in utils.get_bin_ranges(rng, n, FS)]
+    wb, ww = plan.add_tdwindow(0, 16000), plan.add_tdwindow(16000, 20000)
+    out = plan.process(torch.as_tensor(x32, device="cuda:0")).cpu().numpy().astype(np.float64)
+    for i, name in zip(ids, names):
+        assert np.allclose(out[:, plan.band_offset(i)], want[name], rtol=2e-5), name
+    o = plan.tdwindow_offset(ww)
+    assert np.allclose(out[:, o + 4], x64[:, 16000:20000].sum(axis=1), rtol=2e-6)
+    assert np.allclose(out[:, o + 5], (x64[:, 16000:20000] ** 2).sum(axis=1), rtol=2e-6)
+    assert np.array_equal(out[:, o + 6], x64[:, 16000]) and np.array_equal(out[:, o + 7], x64[:, 19999])
+    # static-method level
+    vb, i0, rl = 190.6e-9, 88e-9, 8.8e-3
+    e_ref = orc.energyabsorbed(x64, FS, vb, i0, rl, 16000, 20000)
+    e = FE.energyabsorbed(x32, FS, vb, i0, rl, window_min_index=16000, window_max_index=20000)
+    assert np.allclose(e["energyabsorbed"], e_ref, rtol=2e-4, atol=1e-6 * np.abs(e_ref).max())
+    ob = OFBase(FS)
+    ob.update_signal("A", x32)
+    r = FE.psd_amp("A", ob, f_lims=f_lims)
+    assert set(r) == {f"psd_amp_{nm}" for nm in names}
+    for nm in names:
+        assert np.allclose(r[f"psd_amp_{nm}"], want[nm], rtol=2e-5)
+    with pytest.raises(ValueError):
+        FE.psd_amp("A", ob)
+    # batched driver with the reference's YAML keys
+    yaml_txt = """
+A:
+    of1x1_nodelay:
+        run: True
+        template_tag: default
+    psd_amp:
+        run: True
+        f_lims: [[45.0, 75.0], [300.0, 500.0], [3000, 9000]]
+    energyabsorbed:
+        run: True
+        i0: 88e-9
+        rl: 8.8e-3
+        vb: 190.6e-9
+        window_min_from_trig_usec: -100
+        window_max_from_trig_usec: 1000
+"""
+    fdA = FilterData()
+    fdA.set_template("A", tmpl, sample_rate=FS, pretrigger_length_samples=pre)
+    fdA.set_psd("A", J, np.fft.fftfreq(n, d=1 / FS), sample_rate=FS)
+    fp = FeatureProcessing(yaml_txt, fdA, ["A"], FS, nb_samples=n, nb_pretrigger_samples=pre,
+                           engine=engine if engine == "rocfft" else "auto")
+    df = fp.process(x32)
+    assert np.allclose(df["psd_amp_45_75_A"], want["45_75"], rtol=2e-5)
+    assert np.allclose(df["psd_amp_3000_9000_A"], want["3000_9000"], rtol=2e-5)
+    lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_trig_usec=-100,
+                                    window_max_from_trig_usec=1000)
+    e_ref = orc.energyabsorbed(x64, FS, 190.6e-9, 88e-9, 8.8e-3, lo, hi)
+    assert np.allclose(df["energyabsorbed_A"], e_ref, rtol=2e-4, atol=1e-6 * np.abs(e_ref).max())
