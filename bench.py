@@ -112,14 +112,15 @@ def main():
     maxB = int((free - (6 << 30)) // (N_SAMPLES * 4 + 64))
     if B > maxB:
         B = maxB
-    sigma = float(np.sqrt(np.median(psd) * FS))
     traces = torch.empty((B, N_SAMPLES), dtype=torch.float32, device=dev)
     chunk = 1 << 16
     for b0 in range(0, B, chunk):     # counter-based: (seed, global event index)
         nb = min(chunk, B - b0)
-        synth_traces(nb, N_SAMPLES, tmpl, sigma, 3 * ft.ampres, 300 * ft.ampres, 0.5,
+        # v = A roll(template, d) + coloured noise drawn from J; A log-uniform
+        # in [3, 300] sigma_A for half of the events, d uniform in [-2000, 2000]
+        synth_traces(nb, N_SAMPLES, tmpl, 0.0, 3 * ft.ampres, 300 * ft.ampres, 0.5,
                      2000, seed=2026, first_index=rank * B + b0, device=local_rank,
-                     out=traces[b0:b0 + nb], return_truth=False)
+                     out=traces[b0:b0 + nb], return_truth=False, psd=psd, fs=FS)
     plan = OFPlan(N_SAMPLES, pre, FS, max_batch=8192, device=local_rank,
                   engine=args.engine)
     plan.set_filter(0, ft)

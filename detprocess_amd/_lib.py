@@ -46,6 +46,10 @@ _SYMBOLS = [
     ("ofx_synth_traces", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                    C.c_ulonglong, _p]),
+    ("ofx_synth_traces_psd", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p, _p,
+                                       C.c_float, C.c_float, C.c_float, C.c_int,
+                                       C.c_ulonglong, _p]),
+    ("ofx_synth_release", C.c_int, []),
     ("ofx_plan_kernel_time", C.c_int, [_p, C.POINTER(C.c_double),
                                        C.POINTER(C.c_longlong)]),
     ("ofx_plan_enable_timing", C.c_int, [_p, C.c_int]),

@@ -85,6 +85,149 @@ __global__ __launch_bounds__(256) void k_synth(float* __restrict__ traces,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Coloured noise: noise = irfft(sqrt(J N fs / 2) (xi1 + i xi2)).
+// k_spectrum draws the one-sided spectrum, rocFFT C2R (unnormalised) turns it into
+// the trace, k_add_pulse adds A * roll(template, d).  noise_amp[k] already carries
+// the 1/N of NumPy's irfft.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spectrum(float2* __restrict__ spec, long long first,
+                                                  int K, const float* __restrict__ noise_amp,
+                                                  unsigned long long seed) {
+    const long long b = blockIdx.x;
+    const unsigned long long gid = (unsigned long long)(first + b);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    float2* sp = spec + (size_t)b * K;
+    for (int kk = threadIdx.x; 2 * kk < K; kk += 256) {
+        uint32_t r[4];
+        philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)kk, 2u, k0, k1, r);
+        const float r0 = sqrtf(-2.0f * logf(u01(r[0])));
+        float s, c;
+        sincospif(2.0f * u01(r[1]), &s, &c);
+        const float r1 = sqrtf(-2.0f * logf(u01(r[2])));
+        float s2, c2;
+        sincospif(2.0f * u01(r[3]), &s2, &c2);
+        const int ka = 2 * kk, kb = 2 * kk + 1;
+        float2 va = make_float2(r0 * c, r0 * s), vb = make_float2(r1 * c2, r1 * s2);
+        // DC and Nyquist are real with variance 2 (synth.coloured_noise)
+        if (ka == 0 || ka == K - 1) va = make_float2(va.x * 1.41421356f, 0.0f);
+        if (kb == K - 1) vb = make_float2(vb.x * 1.41421356f, 0.0f);
+        sp[ka] = make_float2(va.x * noise_amp[ka], va.y * noise_amp[ka]);
+        if (kb < K) sp[kb] = make_float2(vb.x * noise_amp[kb], vb.y * noise_amp[kb]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_add_pulse(float* __restrict__ traces,
+                                                   float* __restrict__ truth, long long first,
+                                                   int N, const float* __restrict__ tmpl,
+                                                   float amp_lo, float amp_hi,
+                                                   float pulse_fraction, int max_delay,
+                                                   unsigned long long seed) {
+    const long long b = blockIdx.x;
+    const unsigned long long gid = (unsigned long long)(first + b);
+    uint32_t r[4];
+    philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), 0xFFFFFFFFu, 0u, (uint32_t)seed,
+               (uint32_t)(seed >> 32), r);
+    float amp = 0.0f;
+    if (u01(r[0]) <= pulse_fraction) amp = amp_lo * expf(u01(r[1]) * logf(amp_hi / amp_lo));
+    int delay = 0;
+    if (max_delay > 0) delay = (int)(r[2] % (uint32_t)(2 * max_delay + 1)) - max_delay;
+    if (truth && threadIdx.x == 0) {
+        truth[2 * b] = amp;
+        truth[2 * b + 1] = (float)delay;
+    }
+    if (amp == 0.0f) return;
+    float* t = traces + (size_t)b * N;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        int src = n - delay;
+        if (src < 0) src += N;
+        if (src >= N) src -= N;
+        t[n] = fmaf(amp, tmpl[src], t[n]);
+    }
+}
+
+struct SynthFft {
+    int n = 0, batch = 0;
+    rocfft_plan c2r = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* work = nullptr;
+    float2* spec = nullptr;
+};
+static SynthFft g_sfft;
+
+extern "C" int ofx_synth_release(void) {
+    if (g_sfft.c2r) rocfft_plan_destroy(g_sfft.c2r);
+    if (g_sfft.info) rocfft_execution_info_destroy(g_sfft.info);
+    if (g_sfft.work) (void)hipFree(g_sfft.work);
+    if (g_sfft.spec) (void)hipFree(g_sfft.spec);
+    g_sfft = SynthFft();
+    return OFX_OK;
+}
+
+extern "C" int ofx_synth_traces_psd(float* traces, float* truth, long long n_traces,
+                                    long long first_index, int n_samples,
+                                    const float* template_td, const float* noise_amp,
+                                    float amp_lo, float amp_hi, float pulse_fraction,
+                                    int max_delay, unsigned long long seed, void* stream) {
+    if (!traces || !template_td || !noise_amp || n_traces < 0 || n_samples < 8 ||
+        (n_samples & 1) || !(amp_lo > 0) || !(amp_hi >= amp_lo) || max_delay < 0 ||
+        max_delay >= n_samples) {
+        ofx_set_error("ofx_synth_traces_psd: bad argument");
+        return OFX_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int K = n_samples / 2 + 1;
+    const int CH = 2048;                                 // traces per FFT batch
+    if (g_sfft.n != n_samples) {
+        ofx_synth_release();
+        OFX_FFT(rocfft_setup());
+        size_t len = (size_t)n_samples;
+        OFX_FFT(rocfft_plan_create(&g_sfft.c2r, rocfft_placement_notinplace,
+                                   rocfft_transform_type_real_inverse, rocfft_precision_single,
+                                   1, &len, (size_t)CH, nullptr));
+        size_t wb = 0;
+        OFX_FFT(rocfft_plan_get_work_buffer_size(g_sfft.c2r, &wb));
+        OFX_FFT(rocfft_execution_info_create(&g_sfft.info));
+        if (wb) {
+            OFX_HIP(hipMalloc(&g_sfft.work, wb));
+            OFX_FFT(rocfft_execution_info_set_work_buffer(g_sfft.info, g_sfft.work, wb));
+        }
+        OFX_HIP(hipMalloc(&g_sfft.spec, sizeof(float2) * (size_t)CH * K));
+        g_sfft.n = n_samples;
+        g_sfft.batch = CH;
+    }
+    OFX_FFT(rocfft_execution_info_set_stream(g_sfft.info, st));
+    // the C2R plan has a fixed batch: a partial last chunk goes through a bounce buffer
+    float* bounce = nullptr;
+    for (long long b0 = 0; b0 < n_traces; b0 += CH) {
+        const int nb = (int)((n_traces - b0 < CH) ? (n_traces - b0) : CH);
+        hipLaunchKernelGGL(k_spectrum, dim3(nb), dim3(256), 0, st, g_sfft.spec, first_index + b0,
+                           K, noise_amp, seed);
+        float* dst = traces + (size_t)b0 * n_samples;
+        if (nb < CH) {
+            OFX_HIP(hipMalloc(&bounce, sizeof(float) * (size_t)CH * n_samples));
+            dst = bounce;
+        }
+        void* in[1] = {(void*)g_sfft.spec};
+        void* out[1] = {(void*)dst};
+        OFX_FFT(rocfft_execute(g_sfft.c2r, in, out, g_sfft.info));
+        if (nb < CH)
+            OFX_HIP(hipMemcpyAsync(traces + (size_t)b0 * n_samples, bounce,
+                                   sizeof(float) * (size_t)nb * n_samples,
+                                   hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_add_pulse, dim3(nb), dim3(256), 0, st,
+                           traces + (size_t)b0 * n_samples, truth ? truth + 2 * b0 : nullptr,
+                           first_index + b0, n_samples, template_td, amp_lo, amp_hi,
+                           pulse_fraction, max_delay, seed);
+    }
+    OFX_HIP(hipGetLastError());
+    if (bounce) {
+        OFX_HIP(hipStreamSynchronize(st));
+        (void)hipFree(bounce);
+    }
+    return OFX_OK;
+}
+
 extern "C" int ofx_synth_traces(float* traces, float* truth, long long n_traces,
                                 long long first_index, int n_samples,
                                 const float* template_td, float sigma, float amp_lo,

@@ -206,8 +206,13 @@ class OFPlan:
 
 def synth_traces(n_traces, n_samples, template, sigma, amp_lo, amp_hi,
                  pulse_fraction=0.5, max_delay=2000, seed=0, first_index=0,
-                 device=0, out=None, return_truth=True):
-    """Device-side synthetic events (ofx_synth_traces): returns (traces, truth)."""
+                 device=0, out=None, return_truth=True, psd=None, fs=None):
+    """Device-side synthetic events: returns (traces, truth).
+
+    psd=None: white noise of standard deviation ``sigma`` (ofx_synth_traces).
+    psd=two-sided PSD J (A^2/Hz, fftfreq order) with ``fs``: coloured Gaussian noise
+    irfft(sqrt(J N fs / 2) xi) as SURVEY.md section 8d prescribes (ofx_synth_traces_psd).
+    """
     torch = _torch()
     lib = _lib.load()
     dev = torch.device("cuda", device)
@@ -217,6 +222,18 @@ def synth_traces(n_traces, n_samples, template, sigma, amp_lo, amp_hi,
         if return_truth else None
     t = torch.as_tensor(np.asarray(template, dtype=np.float32), device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    if psd is not None:
+        K = n_samples // 2 + 1
+        J1 = np.asarray(psd, dtype=np.float64)[:K]
+        namp = torch.as_tensor((np.sqrt(J1 * n_samples * float(fs) / 2.0) / n_samples)
+                               .astype(np.float32), device=dev)
+        _lib.check(lib.ofx_synth_traces_psd(
+            out.data_ptr(), truth.data_ptr() if truth is not None else None, int(n_traces),
+            int(first_index), int(n_samples), t.data_ptr(), namp.data_ptr(), float(amp_lo),
+            float(amp_hi), float(pulse_fraction), int(max_delay), int(seed),
+            C.c_void_p(stream)), "ofx_synth_traces_psd")
+        torch.cuda.current_stream(dev).synchronize()
+        return out, truth
     _lib.check(lib.ofx_synth_traces(out.data_ptr(),
                                     truth.data_ptr() if truth is not None else None,
                                     int(n_traces), int(first_index), int(n_samples),

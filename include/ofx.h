@@ -187,6 +187,19 @@ int ofx_synth_traces(float* traces, float* truth, long long n_traces,
                      float amp_hi, float pulse_fraction, int max_delay,
                      unsigned long long seed, void* stream);
 
+/*
+ * Same events with COLOURED Gaussian noise consistent with a PSD:
+ * noise = irfft(sqrt(J N fs / 2) (xi1 + i xi2)).  noise_amp: device float[n/2+1] =
+ * sqrt(J_k N fs / 2) / N (the 1/N of NumPy's irfft folded in).  Uses a cached rocFFT
+ * C2R plan and spectrum buffer; ofx_synth_release() frees them.
+ */
+int ofx_synth_traces_psd(float* traces, float* truth, long long n_traces,
+                         long long first_index, int n_samples, const float* template_td,
+                         const float* noise_amp, float amp_lo, float amp_hi,
+                         float pulse_fraction, int max_delay, unsigned long long seed,
+                         void* stream);
+int ofx_synth_release(void);
+
 /* average GPU time (ms) of the dominant kernel over the launches recorded since
  * the last call, measured with HIP events on the launch stream; resets the
  * accumulator.  n_launches receives the launch count. */

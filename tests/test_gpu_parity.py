@@ -217,3 +217,41 @@ def test_full_size_properties():
     ref = orc.process_events(orc.OFFilter(tmpl, psd, FS, pre), xs.astype(np.float64), "unconstrained")
     check_search(a[torch.as_tensor(idx, device=x.device)].cpu().numpy().astype(np.float64), 0, ref,
                  "", ft.ampres, FS, "full-size sample")
+
+
+def test_coloured_noise_generator_matches_its_psd():
+    """ofx_synth_traces_psd draws noise = irfft(sqrt(J N fs / 2) xi): through the
+    optimal filter built from the same J, E[chi2_0] = N - 1 (AC coupling) and the
+    zero-delay amplitude has unit variance in units of ampres."""
+    import torch
+    from detprocess_amd import OFPlan, synth_traces
+    n, pre, B = 32768, 16384, 6000
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    ft = build_filter(tmpl, psd, FS, pre)
+    x, truth = synth_traces(B, n, tmpl, 0.0, 3 * ft.ampres, 300 * ft.ampres, 0.0, 2000, seed=4,
+                            psd=psd, fs=FS)
+    assert float(truth[:, 0].abs().max()) == 0.0           # pulse_fraction = 0
+    plan = OFPlan(n, pre, FS, max_batch=4096, device=0)
+    plan.set_filter(0, ft)
+    s = plan.add_search(0, "nodelay")
+    out = plan.process(x)
+    o = plan.search_offset(0, s)
+    chi0 = out[:, o + 4].double()
+    a0 = (out[:, o + 0] / ft.ampres).double()
+    assert abs(float(chi0.mean()) / (n - 1) - 1.0) < 5e-3
+    assert abs(float(chi0.std()) / np.sqrt(2.0 * (n - 1)) - 1.0) < 0.1
+    assert abs(float(a0.std()) - 1.0) < 0.05 and abs(float(a0.mean())) < 0.06
+    # reproducible from (seed, global index): a shard equals the same rows of the whole
+    y, _ = synth_traces(100, n, tmpl, 0.0, 3 * ft.ampres, 300 * ft.ampres, 0.0, 2000, seed=4,
+                        first_index=2500, psd=psd, fs=FS)
+    assert torch.equal(y, x[2500:2600])
+    # with pulses: injected amplitude comes back within the filter resolution
+    z, tr = synth_traces(2048, n, tmpl, 0.0, 20 * ft.ampres, 300 * ft.ampres, 1.0, 2000, seed=5,
+                         psd=psd, fs=FS)
+    plan2 = OFPlan(n, pre, FS, max_batch=4096, device=0)
+    plan2.set_filter(0, ft)
+    plan2.add_search(0, "delay")
+    r = plan2.process(z)
+    assert float(((r[:, 7] - pre - tr[:, 1]).abs() <= 3).float().mean()) > 0.99
+    assert float((((r[:, 0] - tr[:, 0]) / ft.ampres).abs() < 5).float().mean()) > 0.995
