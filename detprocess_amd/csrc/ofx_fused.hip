@@ -214,6 +214,35 @@ __device__ __forceinline__ float middle_slots(float2 (&d)[NV], __amdgpu_buffer_r
     return chi;
 }
 
+// Same, with block B (d[O+16 .. O+32)) parked in LDS while the slots run: used when a
+// workgroup has only 128 VGPRs (one virtual thread per thread, two workgroups per CU).
+// xs: this thread's 16-entry column of the exchange buffer (element j at xs[j * FT]).
+template <int O>
+__device__ __forceinline__ float middle_slots_staged(float2 (&d)[NV],
+                                                     __amdgpu_buffer_rsrc_t rmid, int v,
+                                                     FusedLds& L, float2* xs) {
+    float4 ta[2], tb[2];
+    const int vo = v * 16;
+    ta[0] = buf_ld4(rmid, vo, 0);
+    tb[0] = buf_ld4(rmid, vo, 16 * 8192);
+    float2 zn = xs[15 * FT];
+    float chi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float2 zp = zn;
+        if (j + 1 < 16) {
+            ta[(j + 1) & 1] = buf_ld4(rmid, vo, (j + 1) * 8192);
+            tb[(j + 1) & 1] = buf_ld4(rmid, vo, (16 + j + 1) * 8192);
+            zn = xs[(15 - (j + 1)) * FT];
+        }
+        float2 xk2;
+        chi += mid_slot(d[O + j], zp, ta[j & 1], tb[j & 1], xk2);
+        xs[(15 - j) * FT] = zp;
+        if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
+    }
+    return chi;
+}
+
 // Inter-stage twiddles w_M^{n' k1} (F1: multiply, I1: multiply by the conjugate).
 // t1q[kq][vt] packs (w^{2kq}, w^{2kq+1}); rows are streamed in groups of four.
 struct T1Group {
@@ -320,6 +349,75 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
 #pragma unroll
             for (int j = 0; j < NV; ++j) d[j] = nd[j];
+        }
+    };
+
+    // D1 exchange for one virtual thread per hardware thread and a half-size buffer:
+    // "block-diagonal" passes.  Pass p moves the elements (k1, n2) with
+    // (k1 >> 4) ^ (n2 >> 4) == p, so that in every pass every thread writes 16 values
+    // and reads 16 values (at most 32 complex live).  Writer side of E1: thread n'
+    // (n2 = n' >> 4, so n2 >> 4 = hw = wave >> 2) holds k1 = 0..31; reader side:
+    // thread (k1u, n3u) with k1u >> 4 = hw holds n2 = 0..31.  E4 swaps the roles.
+    // hw is wave-uniform: the two register halves are handled by two code paths behind a
+    // scalar branch (the empty asm keeps the compiler from turning them into selects).
+    constexpr bool DIAG_D1 = (VT == 1) && SPLIT_EXCHANGE;
+    auto exchange_d1 = [&](const Roles& R, bool e4) {
+        float2* xc = reinterpret_cast<float2*>(L.xb);
+        const int hw = __builtin_amdgcn_readfirstlane(R.vt >> 8);
+        const int rowb = (R.k1u & 15) * LD1 + R.n3u;       // (k1u, n3u) side, + 16 n2
+        float2 lo[16], hi[16];                              // new values, halves 0 / 1
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const bool up = (p ^ hw) != 0;                 // upper half of my values moves
+            __syncthreads();
+            if (!e4) {                                     // E1: n' side writes
+                if (!up) {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xc[j * LD1 + R.vt] = d[j];
+                } else {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xc[j * LD1 + R.vt] = d[16 + j];
+                }
+            } else {                                       // E4: (k1u, n3u) side writes
+                if (!up) {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xc[rowb + 16 * j] = d[j];
+                } else {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) xc[rowb + 16 * (16 + j)] = d[16 + j];
+                }
+            }
+            __syncthreads();
+            if (!e4) {
+                if (!up) {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) lo[j] = xc[rowb + 16 * j];
+                } else {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) hi[j] = xc[rowb + 16 * (16 + j)];
+                }
+            } else {
+                if (!up) {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) lo[j] = xc[j * LD1 + R.vt];
+                } else {
+                    asm volatile("");
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) hi[j] = xc[j * LD1 + R.vt];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d[j] = lo[j];
+            d[16 + j] = hi[j];
         }
     };
 
@@ -465,17 +563,26 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
 
         // ---------------------------------------------------------------- F1
-        {
+        if constexpr (VT == 2) {
             const T1Group g0 = t1_load(t1q, tl, 0);
             const T1Group g1 = t1_load(t1q, tl + FT, 0);
             __builtin_amdgcn_sched_barrier(0);         // keep the requests ahead of the DFTs
             dft<32, -1, NV, 0>(d);
-            if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
+            dft<32, -1, NV, 32 * (VT - 1)>(d);
             t1_apply<false, 0>(d, t1q, tl, g0);
-            if constexpr (VT == 2) t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT, g1);
+            t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT, g1);
+        } else {
+            dft<32, -1, NV, 0>(d);
+            __builtin_amdgcn_sched_barrier(0);         // 128-VGPR build: no early requests
+            t1_apply<false, 0>(d, t1q, tl, t1_load(t1q, tl, 0));
         }
-        exchange([&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; },
-                 [&](int h, int j) { return RR(h).e1r(j); }, [&](int h, int) { return VT == 2 ? h : (RR(h).k1u >> 4); }, HB1);
+        if constexpr (DIAG_D1) {
+            exchange_d1(R0, false);
+        } else {
+            exchange([&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; },
+                     [&](int h, int j) { return RR(h).e1r(j); }, [](int h, int) { return h; },
+                     HB1);
+        }
         // ---------------------------------------------------------------- F2
         dft<32, -1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
@@ -489,7 +596,23 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                  HB2);
         // ------------------------------------------- F3, middle, I3 (registers)
         float chi0p = 0.0f;
-        {
+        constexpr bool STAGE_B = (VT == 1) && SPLIT_EXCHANGE;
+        if constexpr (STAGE_B) {
+            dft<16, -1, NV, 0>(d);
+            dft<16, -1, NV, 16>(d);
+            const float2 a8 = d[8];
+            if (wave == 0) perm_in<0>(d, tl == 0);
+            float2* xs = reinterpret_cast<float2*>(L.xb) + tl;
+            __syncthreads();                   // every E2 read is done: the buffer is free
+#pragma unroll
+            for (int j = 0; j < 16; ++j) xs[j * FT] = d[16 + j];
+            chi0p += middle_slots_staged<0>(d, rmid, tl, L, xs);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) d[16 + j] = xs[j * FT];
+            if (wave == 0) chi0p = perm_out<0>(d, tl == 0, a8, tabs, chi0p);
+            dft<16, +1, NV, 0>(d);
+            dft<16, +1, NV, 16>(d);
+        } else {
             dft<16, -1, NV, 0>(d);
             dft<16, -1, NV, 16>(d);
             const float2 a8 = d[8];
@@ -523,13 +646,21 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
         {
-            const T1Group g0 = t1_load(t1q, tl2, 0);
-            const T1Group g1 = t1_load(t1q, tl2 + FT, 0);
-            __builtin_amdgcn_sched_barrier(0);         // requests ahead of the exchange
-            exchange([&](int h, int j) { return QQ(h).e1r(j); },
-                     [&](int h, int) { return VT == 2 ? h : (QQ(h).k1u >> 4); },
-                     [&](int h, int j) { return QQ(h).e1w(j); }, [](int, int j) { return j >> 4; },
-                     HB1);
+            T1Group g0, g1;
+            if constexpr (!DIAG_D1) {                  // requests ahead of the exchange
+                g0 = t1_load(t1q, tl2, 0);
+                g1 = t1_load(t1q, tl2 + FT, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (DIAG_D1) {
+                exchange_d1(Q0, true);
+                g0 = t1_load(t1q, tl2, 0);
+                g1 = g0;
+            } else {
+                exchange([&](int h, int j) { return QQ(h).e1r(j); }, [](int h, int) { return h; },
+                         [&](int h, int j) { return QQ(h).e1w(j); },
+                         [](int, int j) { return j >> 4; }, HB1);
+            }
             // ------------------------------------------------------------ I1
             t1_apply<true, 0>(d, t1q, tl2, g0);
             if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT, g1);
