@@ -9,6 +9,23 @@
 
 #define OFX_WAVE 64
 
+// Wave64 reductions on the VALU with DPP (no LDS crossbar round trips): xor-1 / xor-2
+// inside quads, half-row mirror (8), row mirror (16), row_bcast15 into rows 1 and 3,
+// row_bcast31 into rows 2 and 3; lane 63 then holds the result, which is broadcast as a
+// scalar.  The result is valid (and identical) in every lane.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float ofx_dpp(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src),
+                                                      CTRL, ROW_MASK, 0xf, BOUND));
+}
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ int ofx_dppi(int old, int src) {
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, BOUND);
+}
+#define OFX_DPP_STEPS(X)                                                              \
+    X(0xB1, 0xf) X(0x4E, 0xf) X(0x141, 0xf) X(0x140, 0xf) X(0x142, 0xa) X(0x143, 0xc)
+
+
 // ------------------------------------------------------------- candidates
 // A candidate of the delay fit: key = A^2, rolled index i, amplitude A.
 // Ordering restates NumPy argmin(chi2) on the rolled array: larger A^2 wins
@@ -40,18 +57,24 @@ __device__ __forceinline__ void ofx_cand_take(OfxCand& best, float amp, int idx)
     }
 }
 
+// Wave reduce of a candidate (DPP, result broadcast from lane 63 to every lane).
 __device__ __forceinline__ OfxCand ofx_cand_wave_reduce(OfxCand c) {
-#pragma unroll
-    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) {
-        const float k = __shfl_down(c.key, off, OFX_WAVE);
-        const int i = __shfl_down(c.idx, off, OFX_WAVE);
-        const float a = __shfl_down(c.amp, off, OFX_WAVE);
-        if (ofx_cand_better(k, i, c)) {
-            c.key = k;
-            c.idx = i;
-            c.amp = a;
-        }
+#define STEP(C, M)                                                                    \
+    {                                                                                 \
+        const float k = ofx_dpp<C, M, false>(c.key, c.key);                           \
+        const int i = ofx_dppi<C, M, false>(c.idx, c.idx);                            \
+        const float a = ofx_dpp<C, M, false>(c.amp, c.amp);                           \
+        if (ofx_cand_better(k, i, c)) {                                               \
+            c.key = k;                                                                \
+            c.idx = i;                                                                \
+            c.amp = a;                                                                \
+        }                                                                             \
     }
+    OFX_DPP_STEPS(STEP)
+#undef STEP
+    c.key = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.key), 63));
+    c.idx = __builtin_amdgcn_readlane(c.idx, 63);
+    c.amp = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c.amp), 63));
     return c;
 }
 
@@ -76,19 +99,22 @@ __device__ __forceinline__ OfxCand ofx_cand_block_reduce(OfxCand c, OfxCand* scr
 }
 
 __device__ __forceinline__ float ofx_wave_sum(float v) {
-#pragma unroll
-    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, OFX_WAVE);
-    return v;
+#define STEP(C, M) v += ofx_dpp<C, M, true>(0.0f, v);
+    OFX_DPP_STEPS(STEP)
+#undef STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float ofx_wave_max(float v) {
-#pragma unroll
-    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, OFX_WAVE));
-    return v;
+#define STEP(C, M) v = fmaxf(v, ofx_dpp<C, M, false>(v, v));
+    OFX_DPP_STEPS(STEP)
+#undef STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float ofx_wave_min(float v) {
-#pragma unroll
-    for (int off = OFX_WAVE / 2; off > 0; off >>= 1) v = fminf(v, __shfl_down(v, off, OFX_WAVE));
-    return v;
+#define STEP(C, M) v = fminf(v, ofx_dpp<C, M, false>(v, v));
+    OFX_DPP_STEPS(STEP)
+#undef STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Block sum; result valid in every thread.  scratch: >= nthreads/64 floats.

@@ -22,7 +22,9 @@
 // resident per CU so that one computes while the other sits in LDS / barrier / HBM
 // waits, and every thread has two independent instruction streams).
 #include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "ofx_common.h"
 #include "ofx_device.h"
@@ -67,9 +69,24 @@ struct FusedLds {
     float tdred[OFX_MAX_TDWIN][4][NWAVE];   // time-domain window partials
     OfxCand cand[NWAVE];
     OfxCand sres[OFX_MAX_SEARCHES];
+    OfxCand fin[OFX_MAX_SEARCHES];          // resolved fit per search
+    float lowp[OFX_MAX_SEARCHES][NWAVE];    // low-frequency chi2 per wave
     float bcast[8];
 };
 static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
+
+#ifdef OFX_STAMPS
+#define STAMP(i)                                                                    \
+    do {                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
+        if (tid == 0) { stamp_acc[i] += t_ - stamp_prev; }                          \
+        stamp_prev = t_;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
 
 struct FusedTabs {
     const float2* t1;     // [16][512] float4 rows (w_M^{n' 2kq}, w_M^{n' (2kq+1)})
@@ -78,6 +95,7 @@ struct FusedTabs {
     const float4* midB;   // [16][512]  (conj(W_p).x/2, conj(W_p).y/2, g_k', g_p')
     float2 wq;            // W_{M/2}  (the self-paired bin k = M/2)
     float gq;             // g_{M/2}
+    unsigned long long* dbg;   // OFX_STAMPS diagnostic build only
 };
 
 __device__ __forceinline__ int partner_block(int v) { return v == 0 ? 512 : 1024 - v; }
@@ -455,6 +473,10 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     // registers of the current one are dead (after the arg-max), so that its HBM
     // latency hides under the rest of the tail; `have` = d already holds trace b.
     bool have = false;
+#ifdef OFX_STAMPS
+    unsigned long long stamp_acc[16] = {0};
+    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
         float* row = out + (size_t)b * pd.row;
         if (valid && !valid[b]) {
@@ -469,6 +491,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         const Roles R0(tl), R1(tl + FT);
         auto RR = [&](int h) -> const Roles& { return h == 0 ? R0 : R1; };
 
+        STAMP(0);                                // loop overhead / previous tail remainder
         if (!have) load_trace(b);               // cold start / after an invalid event
 
         // ------------------------------------------------ time-domain windows
@@ -562,6 +585,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             continue;
         }
 
+        STAMP(1);                                // wait for the trace + TD windows
         // ---------------------------------------------------------------- F1
         if constexpr (VT == 2) {
             const T1Group g0 = t1_load(t1q, tl, 0);
@@ -576,6 +600,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             __builtin_amdgcn_sched_barrier(0);         // 128-VGPR build: no early requests
             t1_apply<false, 0>(d, t1q, tl, t1_load(t1q, tl, 0));
         }
+        STAMP(2);                                // F1
         if constexpr (DIAG_D1) {
             exchange_d1(R0, false);
         } else {
@@ -583,6 +608,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                      [&](int h, int j) { return RR(h).e1r(j); }, [](int h, int) { return h; },
                      HB1);
         }
+        STAMP(3);                                // E1
         // ---------------------------------------------------------------- F2
         dft<32, -1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
@@ -591,9 +617,11 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 #pragma unroll
             for (int k2 = 1; k2 < 32; ++k2)
                 d[32 * h + k2] = cmul(d[32 * h + k2], L.t2[k2 * 16 + RR(h).n3u]);
+        STAMP(4);                                // F2
         exchange([&](int h, int j) { return RR(h).e2w(j); }, [](int, int j) { return j >> 4; },
                  [&](int h, int j) { return RR(h).e2r(j); }, [](int, int j) { return j >> 4; },
                  HB2);
+        STAMP(5);                                // E2
         // ------------------------------------------- F3, middle, I3 (registers)
         float chi0p = 0.0f;
         constexpr bool STAGE_B = (VT == 1) && SPLIT_EXCHANGE;
@@ -630,6 +658,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             dft<16, +1, NV, O>(d);
             dft<16, +1, NV, O + 16>(d);
         }
+        STAMP(6);                                // F3 + middle + I3
         int tl2 = tid;
         asm volatile("" : "+v"(tl2));          // no CSE of addresses across the middle
         const Roles Q0(tl2), Q1(tl2 + FT);
@@ -637,6 +666,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         exchange([&](int h, int j) { return QQ(h).e2r(j); }, [](int, int j) { return j >> 4; },
                  [&](int h, int j) { return QQ(h).e2w(j); }, [](int, int j) { return j >> 4; },
                  HB2);
+        STAMP(7);                                // E3
         // ---------------------------------------------------------------- I2
 #pragma unroll
         for (int h = 0; h < VT; ++h)
@@ -645,6 +675,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 d[32 * h + k2] = cmulc(d[32 * h + k2], L.t2[k2 * 16 + QQ(h).n3u]);
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
+        STAMP(8);                                // I2
         {
             T1Group g0, g1;
             if constexpr (!DIAG_D1) {                  // requests ahead of the exchange
@@ -661,6 +692,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                          [&](int h, int j) { return QQ(h).e1w(j); },
                          [](int, int j) { return j >> 4; }, HB1);
             }
+            STAMP(9);                            // E4
             // ------------------------------------------------------------ I1
             t1_apply<true, 0>(d, t1q, tl2, g0);
             if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT, g1);
@@ -678,6 +710,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             continue;
         }
 #endif
+        STAMP(10);                               // I1
         // ------------------------------------------------------------- tail
         // (thread ids of the tail come from an opaque copy: its LDS / table addresses are
         // recomputed here instead of being hoisted out of the loop and spilled)
@@ -825,15 +858,10 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
         }
 
-        // d is dead from here on: request the next trace
-        {
-            const long long bn = b + gridDim.x;
-            have = (bn < n_traces) && !(valid && !valid[bn]);
-            if (have) load_trace(bn);
-        }
-
+        // Per search: resolve the fit and every thread's share of the low-frequency chi2
+        // (the last consumers of VMEM-loaded values), parked per wave in LDS ...
         for (int q = 0; q < sd.n_search; ++q) {
-            const OfxSearchDev sq = sd.search[q];
+            const OfxSearchDev& sq = sd.search[q];
             OfxCand best;
             const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
                               sq.hi == FN;
@@ -847,7 +875,6 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 if constexpr (FEAT & 1) best = L.sres[q];
                 else best = ofx_cand_none();
             }
-            // low-frequency chi2 at (amp, t0)
             const int dl = best.idx - pre;
             float low = 0.0f;
 #pragma unroll
@@ -861,16 +888,32 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 }
             }
             low = ofx_wave_sum(low);
-            __syncthreads();
-            if (lane_t == 0) L.red[2][wave_t] = low;
-            __syncthreads();
-            if (tt == 0) {
+            if (lane_t == 0) L.lowp[q][wave_t] = low;
+            if (tt == 0) L.fin[q] = best;
+        }
+        STAMP(11);                               // tail A: max, reductions, arg-max, lowchi2 terms
+        // ... then d and every table value are dead: request the next trace.  Nothing
+        // below waits on vector memory, so the HBM latency hides under the epilogue and
+        // the first stages of the other workgroup.
+        {
+            const long long bn = b + gridDim.x;
+            have = (bn < n_traces) && !(valid && !valid[bn]);
+            if (have) load_trace(bn);
+        }
+        __syncthreads();
+        if (tt == 0) {
+            for (int q = 0; q < sd.n_search; ++q) {
                 float lw = 0.0f;
-                for (int w = 0; w < NWAVE; ++w) lw += L.red[2][w];
-                ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, lw);
+                for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
+                ofx_write_search(row, sd.search[q], sd, pd.inv_fs, pre, chi0, L.fin[q], lw);
             }
         }
+        STAMP(12);                               // tail B: lowchi2 + row write
     }
+#ifdef OFX_STAMPS
+    if (tid == 0 && tabs.dbg)
+        for (int i = 0; i < 16; ++i) tabs.dbg[blockIdx.x * 16 + i] = stamp_acc[i];
+#endif
 }
 
 }  // namespace
@@ -970,12 +1013,47 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
         attr_set = true;
     }
     long long grid = (long long)p->cu_count * WG_PER_CU;
+#ifdef OFX_STAMPS
+    if (const char* e = getenv("OFX_DIAG_WGPC")) grid = (long long)p->cu_count * atoi(e);
+#endif
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
+#ifdef OFX_STAMPS
+    static unsigned long long* d_dbg = nullptr;
+    if (!d_dbg) (void)hipMalloc(&d_dbg, sizeof(unsigned long long) * 16 * 4096);
+    (void)hipMemsetAsync(d_dbg, 0, sizeof(unsigned long long) * 16 * 4096, st);
+    FusedTabs tabs2 = tabs;
+    tabs2.dbg = d_dbg;
+    size_t lds_bytes = sizeof(FusedLds);
+    if (getenv("OFX_DIAG_WGPC") && atoi(getenv("OFX_DIAG_WGPC")) == 1) {
+        lds_bytes = 100 * 1024;   // forces one workgroup per CU
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    }
+    hipLaunchKernelGGL(k_fused<FEAT>, dim3((unsigned)grid), dim3(FT), lds_bytes, st, pd,
+                       sd, tabs2, d_traces, d_valid, n, d_out);
+    {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(16 * grid);
+        (void)hipMemcpy(h.data(), d_dbg, sizeof(unsigned long long) * 16 * grid,
+                        hipMemcpyDeviceToHost);
+        double tot[16] = {0};
+        for (long long b = 0; b < grid; ++b)
+            for (int i = 0; i < 16; ++i) tot[i] += (double)h[b * 16 + i];
+        const double per = (double)n;   // cycles per trace (summed over WGs / traces)
+        fprintf(stderr, "[stamps] cycles per trace per WG:");
+        const char* nm[13] = {"loop", "load+td", "F1", "E1", "F2", "E2", "mid", "E3", "I2",
+                              "E4", "I1", "tailA", "tailB"};
+        double sum = 0;
+        for (int i = 0; i < 13; ++i) { fprintf(stderr, " %s=%.0f", nm[i], tot[i] / per); sum += tot[i] / per; }
+        fprintf(stderr, " | total=%.0f\n", sum);
+    }
+#else
     hipLaunchKernelGGL(k_fused<FEAT>, dim3((unsigned)grid), dim3(FT), sizeof(FusedLds), st, pd,
                        sd, tabs, d_traces, d_valid, n, d_out);
+#endif
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
