@@ -1,17 +1,50 @@
 // ofx_fft_regs.h -- in-register radix-R DFT building blocks for the FUSED engine.
 //
 // Everything here is fully unrolled at compile time: a thread holds R complex
-// values in VGPRs (float2 x[R] with compile-time indices only) and runs a
-// radix-2 decimation-in-time network on them.  Twiddles inside a block are
-// compile-time constants (32nd roots of unity); a butterfly with a non-trivial
-// twiddle costs 6 FMAs (a' = a + w b by 4 FMAs, b' = 2a - a' by 2), trivial
-// ones 4 adds.  32-point block: 46 trivial + 34 general butterflies = 388 VALU
+// values in VGPRs (cpx x[R] with compile-time indices only) and runs a radix-2
+// decimation-in-time network on them.  A complex value is a 2-vector in an
+// aligned VGPR pair and all arithmetic is packed fp32 (v_pk_add/mul/fma_f32, the
+// re<->im swap and the sign pattern of a multiplication by i ride on the
+// op_sel / neg modifiers): one instruction per complex operation.  A wave that is
+// alone on its SIMD issues one VALU instruction per ~4 cycles, packed or not
+// (tools/micro/valu_mix.hip), so halving the instruction count is what counts.
+// Twiddles inside a block are compile-time constants (32nd roots of unity); a
+// butterfly with a non-trivial twiddle costs 3 packed FMAs (a' = a + w b by two,
+// b' = 2a - a' by one), trivial ones 2.  32-point block: 80 butterflies, 194
 // instructions for 32 complex points.
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 namespace ofxfft {
+
+typedef float cpx __attribute__((ext_vector_type(2)));   // (re, im) in an aligned VGPR pair
+
+__device__ __forceinline__ cpx mk(float re, float im) { return (cpx){re, im}; }
+__device__ __forceinline__ cpx swp(cpx z) { return __builtin_shufflevector(z, z, 1, 0); }
+__device__ __forceinline__ cpx pfma(cpx a, cpx b, cpx c) { return __builtin_elementwise_fma(a, b, c); }
+// The compiler folds whole-vector negation and lane swaps into the packed-instruction
+// modifiers but not a negation of one lane; those forms are spelled out here.
+//   t + a.y * (-w.y, w.x)
+__device__ __forceinline__ cpx pfma_ay_iw(cpx a, cpx w, cpx t) {
+    cpx r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+//   t + a.x * (w.x, -w.y)
+__device__ __forceinline__ cpx pfma_ax_cw(cpx a, cpx w, cpx t) {
+    cpx r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+//   conj(a + b)
+__device__ __forceinline__ cpx conj_sum(cpx a, cpx b) {
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // cos(2 pi j / 32), j = 0..8
 constexpr double kCos32[9] = {
@@ -49,37 +82,34 @@ __host__ __device__ constexpr int ilog2(int v) {
 // One radix-2 DIT butterfly with the constant twiddle w = exp(DIR * 2 pi i NUM/32):
 //   a' = a + w b ,  b' = a - w b.
 template <int NUM, int DIR>
-__device__ __forceinline__ void bfly(float2& a, float2& b) {
+__device__ __forceinline__ void bfly(cpx& a, cpx& b) {
     constexpr int n = ((NUM % 32) + 32) % 32;
     if constexpr (n == 0) {
-        const float2 t = b;
-        b = make_float2(a.x - t.x, a.y - t.y);
-        a = make_float2(a.x + t.x, a.y + t.y);
-    } else if constexpr (n == 8) {
-        // w = DIR * i  ->  w b = DIR * (-b.y, b.x)
-        const float2 t = (DIR > 0) ? make_float2(-b.y, b.x) : make_float2(b.y, -b.x);
-        b = make_float2(a.x - t.x, a.y - t.y);
-        a = make_float2(a.x + t.x, a.y + t.y);
+        const cpx t = b;
+        b = a - t;
+        a = a + t;
     } else if constexpr (n == 16) {
-        const float2 t = b;
-        b = make_float2(a.x + t.x, a.y + t.y);
-        a = make_float2(a.x - t.x, a.y - t.y);
-    } else if constexpr (n == 24) {
-        const float2 t = (DIR > 0) ? make_float2(b.y, -b.x) : make_float2(-b.y, b.x);
-        b = make_float2(a.x - t.x, a.y - t.y);
-        a = make_float2(a.x + t.x, a.y + t.y);
+        const cpx t = b;
+        b = a + t;
+        a = a - t;
+    } else if constexpr (n == 8 || n == 24) {
+        // w = +-i  ->  w b = sg * (-b.y, b.x)
+        constexpr float sg = (n == 8) ? (float)DIR : (float)-DIR;
+        const cpx t = swp(b);
+        b = pfma(t, mk(sg, -sg), a);
+        a = pfma(t, mk(-sg, sg), a);
     } else {
         constexpr float c = (float)cos32(n);
         constexpr float s = (float)(DIR * sin32(n));
-        const float nx = fmaf(c, b.x, fmaf(-s, b.y, a.x));
-        const float ny = fmaf(c, b.y, fmaf(s, b.x, a.y));
-        b = make_float2(fmaf(2.0f, a.x, -nx), fmaf(2.0f, a.y, -ny));
-        a = make_float2(nx, ny);
+        cpx nn = pfma(b, mk(c, c), a);
+        nn = pfma(swp(b), mk(-s, s), nn);
+        b = pfma(a, mk(2.0f, 2.0f), -nn);
+        a = nn;
     }
 }
 
 template <int R, int TOT, int OFF, int LEN, int G, int J, int DIR>
-__device__ __forceinline__ void stage_j(float2 (&y)[TOT]) {
+__device__ __forceinline__ void stage_j(cpx (&y)[TOT]) {
     if constexpr (J < LEN / 2) {
         constexpr int bits = ilog2(R);
         // element i of the bit-reversed working array lives in y[OFF + brev(i)]
@@ -89,14 +119,14 @@ __device__ __forceinline__ void stage_j(float2 (&y)[TOT]) {
     }
 }
 template <int R, int TOT, int OFF, int LEN, int G, int DIR>
-__device__ __forceinline__ void stage_g(float2 (&y)[TOT]) {
+__device__ __forceinline__ void stage_g(cpx (&y)[TOT]) {
     if constexpr (G < R) {
         stage_j<R, TOT, OFF, LEN, G, 0, DIR>(y);
         stage_g<R, TOT, OFF, LEN, G + LEN, DIR>(y);
     }
 }
 template <int R, int TOT, int OFF, int LEN, int DIR>
-__device__ __forceinline__ void stages(float2 (&y)[TOT]) {
+__device__ __forceinline__ void stages(cpx (&y)[TOT]) {
     if constexpr (LEN <= R) {
         stage_g<R, TOT, OFF, LEN, 0, DIR>(y);
         stages<R, TOT, OFF, LEN * 2, DIR>(y);
@@ -111,22 +141,38 @@ __device__ __forceinline__ void stages(float2 (&y)[TOT]) {
 // register renaming at the end restores natural order.
 // Operates on x[OFF .. OFF+R) of an array of TOT registers.
 template <int R, int DIR, int TOT = R, int OFF = 0>
-__device__ __forceinline__ void dft(float2 (&x)[TOT]) {
+__device__ __forceinline__ void dft(cpx (&x)[TOT]) {
     constexpr int bits = ilog2(R);
     stages<R, TOT, OFF, 2, DIR>(x);
-    float2 t[R];
+    cpx t[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) t[k] = x[OFF + brev(k, bits)];
 #pragma unroll
     for (int k = 0; k < R; ++k) x[OFF + k] = t[k];
 }
 
-// complex helpers
-__device__ __forceinline__ float2 cmul(float2 a, float2 w) {
-    return make_float2(fmaf(a.x, w.x, -a.y * w.y), fmaf(a.x, w.y, a.y * w.x));
+// w * b for the compile-time constant w = exp(DIR * 2 pi i NUM / 32)
+template <int NUM, int DIR>
+__device__ __forceinline__ cpx twmul(cpx b) {
+    constexpr int n = ((NUM % 32) + 32) % 32;
+    if constexpr (n == 0) {
+        return b;
+    } else if constexpr (n == 16) {
+        return -b;
+    } else if constexpr (n == 8 || n == 24) {
+        constexpr float sg = (n == 8) ? (float)DIR : (float)-DIR;
+        return swp(b) * mk(-sg, sg);
+    } else {
+        constexpr float c = (float)cos32(n);
+        constexpr float s = (float)(DIR * sin32(n));
+        return pfma(swp(b), mk(-s, s), b * mk(c, c));
+    }
 }
-__device__ __forceinline__ float2 cmulc(float2 a, float2 w) {   // a * conj(w)
-    return make_float2(fmaf(a.x, w.x, a.y * w.y), fmaf(a.y, w.x, -a.x * w.y));
+
+// complex helpers (two packed instructions each)
+__device__ __forceinline__ cpx cmul(cpx a, cpx w) { return pfma_ay_iw(a, w, a.xx * w); }
+__device__ __forceinline__ cpx cmulc(cpx a, cpx w) {   // a * conj(w)
+    return pfma_ax_cw(a, w, a.yy * swp(w));
 }
 
 }  // namespace ofxfft

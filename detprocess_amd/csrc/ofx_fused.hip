@@ -23,6 +23,7 @@
 // waits, and every thread has two independent instruction streams).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -63,8 +64,8 @@ constexpr int HB2 = 512 * LD2;     // D2 elements per half
 
 struct FusedLds {
     float xb[SPLIT_EXCHANGE ? XBUF_ELEMS : 2 * XBUF_ELEMS];   // exchange buffer / lag dump
-    float2 t2[512];                //  4,096 B   w_512^{n3 k2}, index k2*16+n3
-    float2 xlow[NLOW_MAX + 8];     //  4,160 B   2*X_k for k < 512 (lowchi2)
+    cpx t2[512];                   //  4,096 B   w_512^{n3 k2}, index k2*16+n3
+    cpx xlow[NLOW_MAX + 8];        //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
     float tdred[OFX_MAX_TDWIN][4][NWAVE];   // time-domain window partials
     OfxCand cand[NWAVE];
@@ -72,30 +73,23 @@ struct FusedLds {
     OfxCand fin[OFX_MAX_SEARCHES];          // resolved fit per search
     float lowp[OFX_MAX_SEARCHES][NWAVE];    // low-frequency chi2 per wave
     float bcast[8];
+    cpx perm[32];                           // virtual thread 0's permutation bounce buffer
 };
 static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
 
-#ifdef OFX_STAMPS
-#define STAMP(i)                                                                    \
-    do {                                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                          \
-        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                 \
-        if (tid == 0) { stamp_acc[i] += t_ - stamp_prev; }                          \
-        stamp_prev = t_;                                                            \
-        __builtin_amdgcn_sched_barrier(0);                                          \
-    } while (0)
-#else
-#define STAMP(i)
-#endif
+// Phase markers: an assembly comment (";ofxphase i") to find the phases in the ISA
+// (hipcc -S; tools/isa_phases.py counts instructions per phase).
+#define STAMP(i) asm volatile(";ofxphase " #i)
 
 struct FusedTabs {
-    const float2* t1;     // [16][512] float4 rows (w_M^{n' 2kq}, w_M^{n' (2kq+1)})
+    const float2* t1;     // [5][512] float4 rows of stage-1 twiddle anchors (see T1Anch)
     const float2* t2;     // [32][16]   w_512^{n3 k2}
-    const float4* midA;   // [16][512]  (t_k.x, t_k.y, W_k.x/2, W_k.y/2)
-    const float4* midB;   // [16][512]  (conj(W_p).x/2, conj(W_p).y/2, g_k', g_p')
+    const float4* midW;   // [16][512]  (W_k / 2, conj(W_p) / 2)          slot j, virtual thread v
+    const float2* midG;   // [16][512]  (g_k', g_p')
+    const float2* tbase;  // [512]      T_v = i exp(-2 pi i v / N); T of slot j is T_v w_32^j
+    float2 tb0hi;         // base of virtual thread 0 for its slots j >= 8 (block 512)
     float2 wq;            // W_{M/2}  (the self-paired bin k = M/2)
     float gq;             // g_{M/2}
-    unsigned long long* dbg;   // OFX_STAMPS diagnostic build only
 };
 
 __device__ __forceinline__ int partner_block(int v) { return v == 0 ? 512 : 1024 - v; }
@@ -115,182 +109,190 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, in
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
                        __uint_as_float(v.w));
 }
-__device__ __forceinline__ float2 buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+__device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+    return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+__device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
+__device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
 
 // ---- the pairwise middle step on one (Z_k, Z_p) slot -------------------------
 // in : zk = Z_k, zp = Z_p (p = M - k)      out: zk = Z'_k, zp = Z'_p
-// returns the chi2_0 contribution; xk2 = 2 X_k.
-__device__ __forceinline__ float mid_slot(float2& zk, float2& zp, const float4 ta,
-                                          const float4 tb, float2& xk2) {
-    const float2 t = make_float2(ta.x, ta.y);
-    const float2 wk = make_float2(ta.z, ta.w);
-    const float2 wp = make_float2(tb.x, tb.y);
-    const float2 u = make_float2(zk.x + zp.x, zk.y - zp.y);
-    const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
-    // s = i t w
-    const float2 s = make_float2(-fmaf(t.x, w.y, t.y * w.x), fmaf(t.x, w.x, -t.y * w.y));
-    xk2 = make_float2(u.x - s.x, u.y - s.y);                 // 2 X_k
-    const float2 xp2 = make_float2(u.x + s.x, u.y + s.y);    // 2 conj(X_p)
-    float chi = tb.z * fmaf(xk2.x, xk2.x, xk2.y * xk2.y);
-    chi = fmaf(tb.w, fmaf(xp2.x, xp2.x, xp2.y * xp2.y), chi);
-    const float2 yk = cmul(xk2, wk);
-    const float2 yp = cmul(xp2, wp);
-    const float2 sg = make_float2(yk.x + yp.x, yk.y + yp.y);
-    const float2 df = make_float2(yk.x - yp.x, yk.y - yp.y);
-    // e = i conj(t) df
-    const float2 e = make_float2(-fmaf(t.x, df.y, -t.y * df.x), fmaf(t.x, df.x, t.y * df.y));
-    zk = make_float2(sg.x + e.x, sg.y + e.y);
-    zp = make_float2(sg.x - e.x, -(sg.y - e.y));
-    return chi;
-}
-
-__device__ __forceinline__ float2 sel(bool c, float2 a, float2 b) {
-    return make_float2(c ? a.x : b.x, c ? a.y : b.y);
+// chi accumulates the chi2_0 contribution lane-wise (re^2 and im^2 terms); xk2 = 2 X_k.
+// T = i t_k, tw = (W_k / 2, conj(W_p) / 2), g = (g_k', g_p').  20 packed instructions.
+__device__ __forceinline__ void mid_slot(cpx& zk, cpx& zp, const cpx T, const float4 tw,
+                                         const cpx g, cpx& xk2, cpx& chi) {
+    const cpx wk = lo2(tw), wp = hi2(tw);
+    const cpx u = pfma(zp, mk(1.0f, -1.0f), zk);             // Z_k + conj(Z_p)
+    const cpx w = pfma(zp, mk(-1.0f, 1.0f), zk);             // Z_k - conj(Z_p)
+    const cpx sv = cmul(w, T);                               // i t w
+    xk2 = u - sv;                                            // 2 X_k
+    const cpx xp2 = u + sv;                                  // 2 conj(X_p)
+    chi = pfma(xk2 * xk2, g.xx, chi);
+    chi = pfma(xp2 * xp2, g.yy, chi);
+    const cpx yk = cmul(xk2, wk);
+    const cpx yp = cmul(xp2, wp);
+    const cpx sg = yk + yp;
+    const cpx df = yk - yp;
+    const cpx q = cmulc(df, T);                              // = -(i conj(t) df)
+    zk = sg - q;
+    zp = conj_sum(sg, q);
 }
 
 // Middle step over the 32 values of a virtual thread at d[O .. O+32).
 // A = d[O+0..15] (block k_low = v), B = d[O+16..31] (partner block).  Generic: slot j
 // pairs (A[j], B[15-j]).  Virtual thread 0 (blocks 0 and 512, both self-paired) is
-// brought to the same slot shape by a register permutation (perm_in / perm_out),
-// applied only in the wave that holds it.
-template <int O>
-__device__ __forceinline__ void perm_in(float2 (&d)[NV], bool z) {
-    // genA = [A0[0..7], B0[0..7]] ; genB = [B0[8..15], A0[9..15], A0[0]]
-    float2 n[32];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) n[j] = d[O + j];
-#pragma unroll
-    for (int j = 8; j < 16; ++j) n[j] = sel(z, d[O + 16 + j - 8], d[O + j]);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[O + 16 + 8 + i], d[O + 16 + i]);
-#pragma unroll
-    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[O + (i + 1) % 16], d[O + 16 + i]);
-#pragma unroll
-    for (int j = 0; j < 32; ++j) d[O + j] = n[j];
+// brought to the same slot shape by a permutation of its 32 values (perm_in / perm_out):
+// that one thread bounces them through 256 bytes of LDS, which costs no registers.
+//   genA = [A0[0..7], B0[0..7]] ; genB = [B0[8..15], A0[9..15], A0[0]]
+__device__ constexpr int perm_in_src(int j) {
+    if (j < 8) return j;
+    if (j < 24) return j + 8;                      // genA[8..15] = B0[0..7]; genB[0..7] = B0[8..15]
+    return (j - 16 + 1) % 16;                      // genB[8..15] = A0[9..15], A0[0]
 }
-
+// A0[9..15] = genB[8..14], A0[0] = genA[0] (genB[15] discarded); B0[0..7] = genA[8..15];
+// B0[8..15] = genB[0..7]; A0[8] is the self-paired bin k = M/2, handled by the caller.
+__device__ constexpr int perm_out_src(int j) {
+    if (j < 8) return j;
+    if (j < 16) return 16 + j - 1;                 // j = 8 is overwritten by the caller
+    if (j < 24) return j - 8;
+    return j - 8;
+}
 template <int O>
-__device__ __forceinline__ float perm_out(float2 (&d)[NV], bool z, float2 a8,
-                                          const FusedTabs& tabs, float chi) {
-    // self-paired bin k = M/2 (virtual thread 0, A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
-    const float2 zq = cmulc(a8, tabs.wq);
-    if (z) chi = fmaf(2.0f * tabs.gq, fmaf(a8.x, a8.x, a8.y * a8.y), chi);
-    float2 n[32];
+__device__ __forceinline__ void perm_in(cpx (&d)[NV], bool z, cpx* buf) {
+    if (z) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) n[j] = d[O + j];
-    // A0[8] special, A0[9..15] = genB[8..14], A0[0] = genA[0] (genB[15] discarded)
-    n[8] = sel(z, make_float2(2.0f * zq.x, 2.0f * zq.y), d[O + 8]);
+        for (int j = 0; j < 32; ++j) buf[j] = d[O + j];
 #pragma unroll
-    for (int j = 9; j < 16; ++j) n[j] = sel(z, d[O + 16 + j - 1], d[O + j]);
-    // B0[0..7] = genA[8..15] ; B0[8..15] = genB[0..7]
+        for (int j = 8; j < 32; ++j) d[O + j] = buf[perm_in_src(j)];
+    }
+}
+template <int O>
+__device__ __forceinline__ cpx perm_out(cpx (&d)[NV], bool z, cpx a8, const FusedTabs& tabs,
+                                        cpx chi, cpx* buf) {
+    if (z) {
+        // self-paired bin k = M/2 (A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
+        const cpx zq = cmulc(a8, mk(tabs.wq.x, tabs.wq.y));
+        chi = pfma(a8 * a8, mk(2.0f * tabs.gq, 2.0f * tabs.gq), chi);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) n[16 + i] = sel(z, d[O + 8 + i], d[O + 16 + i]);
+        for (int j = 0; j < 32; ++j) buf[j] = d[O + j];
 #pragma unroll
-    for (int i = 8; i < 16; ++i) n[16 + i] = sel(z, d[O + 16 + i - 8], d[O + 16 + i]);
-#pragma unroll
-    for (int j = 0; j < 32; ++j) d[O + j] = n[j];
+        for (int j = 9; j < 32; ++j) d[O + j] = buf[perm_out_src(j)];
+        d[O + 8] = zq + zq;
+    }
     return chi;
 }
 
-// 16 pair slots; table rows are software-pipelined MID_DEPTH slots ahead.
+// 16 pair slots; table rows are software-pipelined MID_DEPTH slots ahead (L2 latency is
+// ~1k cycles against ~100 cycles of arithmetic per slot).  The twiddle of slot j is the
+// thread's base T_v times the constant w_32^j: only the filter itself comes from memory
+// (24 bytes per slot).  tlo / thi: base for slots j < 8 / j >= 8 (they differ only in
+// virtual thread 0, whose upper slots belong to block 512).
 #ifndef OFX_MID_DEPTH
-#define OFX_MID_DEPTH 2
+#define OFX_MID_DEPTH 4
 #endif
 constexpr int MID_DEPTH = OFX_MID_DEPTH;
+struct MidRsrc {
+    __amdgpu_buffer_rsrc_t w, g;
+};
+template <int O, int J, int NB>
+__device__ __forceinline__ void mid_unrolled(cpx (&d)[NV], const MidRsrc& r, int v, FusedLds& L,
+                                             cpx tlo, cpx thi, float4 (&tw)[NB], cpx (&tg)[NB],
+                                             cpx& chi) {
+    if constexpr (J < 16) {
+        if constexpr (J + MID_DEPTH < 16) {
+            tw[(J + MID_DEPTH) % NB] = buf_ld4(r.w, v * 16, (J + MID_DEPTH) * 8192);
+            tg[(J + MID_DEPTH) % NB] = buf_ld2(r.g, v * 8, (J + MID_DEPTH) * 4096);
+        }
+        const cpx T = twmul<J, -1>(J < 8 ? tlo : thi);
+        cpx xk2;
+        mid_slot(d[O + J], d[O + 16 + 15 - J], T, tw[J % NB], tg[J % NB], xk2, chi);
+        if constexpr (J == 0) L.xlow[v] = xk2;               // 2 X_k, k = v < 512
+        mid_unrolled<O, J + 1, NB>(d, r, v, L, tlo, thi, tw, tg, chi);
+    }
+}
 template <int O>
-__device__ __forceinline__ float middle_slots(float2 (&d)[NV], __amdgpu_buffer_rsrc_t rmid,
-                                              int v, FusedLds& L) {
-    // rmid covers [midA: 16 rows][midB: 16 rows], 8 KiB per row
+__device__ __forceinline__ cpx middle_slots(cpx (&d)[NV], const MidRsrc& r, int v, FusedLds& L,
+                                            cpx tlo, cpx thi, cpx chi) {
     constexpr int NB = MID_DEPTH + 1;
-    float4 ta[NB], tb[NB];
-    const int vo = v * 16;
+    float4 tw[NB];
+    cpx tg[NB];
 #pragma unroll
     for (int j = 0; j < MID_DEPTH; ++j) {
-        ta[j] = buf_ld4(rmid, vo, j * 8192);
-        tb[j] = buf_ld4(rmid, vo, (16 + j) * 8192);
+        tw[j] = buf_ld4(r.w, v * 16, j * 8192);
+        tg[j] = buf_ld2(r.g, v * 8, j * 4096);
     }
-    float chi = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if (j + MID_DEPTH < 16) {
-            ta[(j + MID_DEPTH) % NB] = buf_ld4(rmid, vo, (j + MID_DEPTH) * 8192);
-            tb[(j + MID_DEPTH) % NB] = buf_ld4(rmid, vo, (16 + j + MID_DEPTH) * 8192);
-        }
-#if OFX_MID_DEPTH < 2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        float2 xk2;
-        chi += mid_slot(d[O + j], d[O + 16 + 15 - j], ta[j % NB], tb[j % NB], xk2);
-        if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
-#if OFX_MID_DEPTH < 2
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-    }
+    mid_unrolled<O, 0, NB>(d, r, v, L, tlo, thi, tw, tg, chi);
     return chi;
 }
 
 // Same, with block B (d[O+16 .. O+32)) parked in LDS while the slots run: used when a
 // workgroup has only 128 VGPRs (one virtual thread per thread, two workgroups per CU).
 // xs: this thread's 16-entry column of the exchange buffer (element j at xs[j * FT]).
-template <int O>
-__device__ __forceinline__ float middle_slots_staged(float2 (&d)[NV],
-                                                     __amdgpu_buffer_rsrc_t rmid, int v,
-                                                     FusedLds& L, float2* xs) {
-    float4 ta[2], tb[2];
-    const int vo = v * 16;
-    ta[0] = buf_ld4(rmid, vo, 0);
-    tb[0] = buf_ld4(rmid, vo, 16 * 8192);
-    float2 zn = xs[15 * FT];
-    float chi = 0.0f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        float2 zp = zn;
-        if (j + 1 < 16) {
-            ta[(j + 1) & 1] = buf_ld4(rmid, vo, (j + 1) * 8192);
-            tb[(j + 1) & 1] = buf_ld4(rmid, vo, (16 + j + 1) * 8192);
-            zn = xs[(15 - (j + 1)) * FT];
+template <int O, int J>
+__device__ __forceinline__ void mid_staged_unrolled(cpx (&d)[NV], const MidRsrc& r, int v,
+                                                    FusedLds& L, cpx* xs, cpx tlo, cpx thi,
+                                                    float4 (&tw)[2], cpx (&tg)[2], cpx& zn,
+                                                    cpx& chi) {
+    if constexpr (J < 16) {
+        cpx zp = zn;
+        if constexpr (J + 1 < 16) {
+            tw[(J + 1) & 1] = buf_ld4(r.w, v * 16, (J + 1) * 8192);
+            tg[(J + 1) & 1] = buf_ld2(r.g, v * 8, (J + 1) * 4096);
+            zn = xs[(15 - (J + 1)) * FT];
         }
-        float2 xk2;
-        chi += mid_slot(d[O + j], zp, ta[j & 1], tb[j & 1], xk2);
-        xs[(15 - j) * FT] = zp;
-        if (j == 0) L.xlow[v] = xk2;                         // 2 X_k, k = v < 512
+        const cpx T = twmul<J, -1>(J < 8 ? tlo : thi);
+        cpx xk2;
+        mid_slot(d[O + J], zp, T, tw[J & 1], tg[J & 1], xk2, chi);
+        xs[(15 - J) * FT] = zp;
+        if constexpr (J == 0) L.xlow[v] = xk2;               // 2 X_k, k = v < 512
+        mid_staged_unrolled<O, J + 1>(d, r, v, L, xs, tlo, thi, tw, tg, zn, chi);
     }
+}
+template <int O>
+__device__ __forceinline__ cpx middle_slots_staged(cpx (&d)[NV], const MidRsrc& r, int v,
+                                                   FusedLds& L, cpx* xs, cpx tlo, cpx thi,
+                                                   cpx chi) {
+    float4 tw[2];
+    cpx tg[2];
+    tw[0] = buf_ld4(r.w, v * 16, 0);
+    tg[0] = buf_ld2(r.g, v * 8, 0);
+    cpx zn = xs[15 * FT];
+    mid_staged_unrolled<O, 0>(d, r, v, L, xs, tlo, thi, tw, tg, zn, chi);
     return chi;
 }
 
-// Inter-stage twiddles w_M^{n' k1} (F1: multiply, I1: multiply by the conjugate).
-// t1q[kq][vt] packs (w^{2kq}, w^{2kq+1}); rows are streamed in groups of four.
-struct T1Group {
-    float4 q[4];
+// Inter-stage twiddles w_M^{n' k1} (F1: multiply, I1: multiply by the conjugate), built
+// per virtual thread from ten anchors  B_b = w^{n' b} (b = 1..7),  A_a = w^{8 n' a}
+// (a = 1..3):  w^{n' (8a + b)} = A_a B_b.  80 bytes per virtual thread from L2 instead
+// of 248, one load latency instead of four, and 21 extra complex products (42 packed
+// instructions).  t1a[r][n'] = (anchor 2r, anchor 2r+1), anchors ordered B1..B7, A1..A3.
+struct T1Anch {
+    float4 q[5];
 };
-__device__ __forceinline__ T1Group t1_load(__amdgpu_buffer_rsrc_t t1q, int vt, int g) {
-    T1Group r;
+__device__ __forceinline__ T1Anch t1_load(__amdgpu_buffer_rsrc_t t1a, int vt) {
+    T1Anch r;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r.q[c] = buf_ld4(t1q, vt * 16, (4 * g + c) * 8192);
+    for (int c = 0; c < 5; ++c) r.q[c] = buf_ld4(t1a, vt * 16, c * 8192);
     return r;
 }
-// `cur` = group 0, requested by the caller ahead of the preceding DFT / exchange so
-// that its L2 latency is covered; the remaining groups stream one group ahead.
 template <bool CONJ, int O>
-__device__ __forceinline__ void t1_apply(float2 (&d)[NV], __amdgpu_buffer_rsrc_t t1q, int vt,
-                                         T1Group cur) {
+__device__ __forceinline__ void t1_apply(cpx (&d)[NV], const T1Anch& an) {
+    cpx B[8], A[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        T1Group nxt;
-        if (g < 3) nxt = t1_load(t1q, vt, g + 1);
+    for (int i = 1; i < 8; ++i) B[i] = (i & 1) ? lo2(an.q[(i - 1) >> 1]) : hi2(an.q[(i - 1) >> 1]);
+    A[1] = hi2(an.q[3]);
+    A[2] = lo2(an.q[4]);
+    A[3] = hi2(an.q[4]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int k1 = 8 * g + 2 * c;
-            const float2 w0 = make_float2(cur.q[c].x, cur.q[c].y);
-            const float2 w1 = make_float2(cur.q[c].z, cur.q[c].w);
-            if (k1 != 0) d[O + k1] = CONJ ? cmulc(d[O + k1], w0) : cmul(d[O + k1], w0);
-            d[O + k1 + 1] = CONJ ? cmulc(d[O + k1 + 1], w1) : cmul(d[O + k1 + 1], w1);
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int k1 = 8 * a + b;
+            if (k1 == 0) continue;
+            const cpx w = (a == 0) ? B[b] : (b == 0) ? A[a] : cmul(A[a], B[b]);
+            d[O + k1] = CONJ ? cmulc(d[O + k1], w) : cmul(d[O + k1], w);
         }
-        if (g < 3) cur = nxt;
-    }
 }
 
 // Roles and LDS index maps of one virtual thread.
@@ -321,13 +323,14 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int pre = pd.pre;
-    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 32 * 512 * 8);
-    const __amdgpu_buffer_rsrc_t rmid = make_rsrc(tabs.midA, 2 * 16 * 512 * 16);
+    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 5 * 512 * 16);
+    const MidRsrc rmid = {make_rsrc(tabs.midW, 16 * 512 * 16), make_rsrc(tabs.midG, 16 * 512 * 8)};
+    const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 512 * 8);
 
-    for (int i = tid; i < 512; i += FT) L.t2[i] = tabs.t2[i];
+    for (int i = tid; i < 512; i += FT) L.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
 
     const size_t ev_stride = (size_t)pd.n_channels * FN;
-    float2 d[NV];
+    cpx d[NV];
 
     // LDS exchange of the NV values of a thread.  widx / ridx map (role h, value j) to
     // an element index of the full layout; wpass / rpass give the half (0 / 1) that
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 #ifdef ABL_NOEXCH
         return;
 #endif
-        float2* xc = reinterpret_cast<float2*>(L.xb);
+        cpx* xc = reinterpret_cast<cpx*>(L.xb);
         if constexpr (!SPLIT_EXCHANGE) {
             __syncthreads();                   // earlier readers of xb are done
 #pragma unroll
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 #pragma unroll
                 for (int j = 0; j < 32; ++j) d[32 * h + j] = xc[ridx(h, j)];
         } else {
-            float2 nd[NV];
+            cpx nd[NV];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
                 __syncthreads();               // earlier readers of xb are done
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     // scalar branch (the empty asm keeps the compiler from turning them into selects).
     constexpr bool DIAG_D1 = (VT == 1) && SPLIT_EXCHANGE;
     auto exchange_d1 = [&](const Roles& R, bool e4) {
-        float2* xc = reinterpret_cast<float2*>(L.xb);
+        cpx* xc = reinterpret_cast<cpx*>(L.xb);
         const int hw = __builtin_amdgcn_readfirstlane(R.vt >> 8);
         const int rowb = (R.k1u & 15) * LD1 + R.n3u;       // (k1u, n3u) side, + 16 n2
-        float2 lo[16], hi[16];                              // new values, halves 0 / 1
+        cpx lo[16], hi[16];                                 // new values, halves 0 / 1
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const bool up = (p ^ hw) != 0;                 // upper half of my values moves
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         const float* e = traces + (size_t)bb * ev_stride;
         if constexpr (FEAT & 4) {
 #pragma unroll
-            for (int j = 0; j < NV; ++j) d[j] = make_float2(0.f, 0.f);
+            for (int j = 0; j < NV; ++j) d[j] = mk(0.f, 0.f);
             for (int c = 0; c < pd.n_terms; ++c) {
                 const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + (size_t)pd.chan[c] * FN, FN * 4);
                 const float wgt = pd.weight[c];
@@ -454,9 +457,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 for (int h = 0; h < VT; ++h)
 #pragma unroll
                     for (int n1 = 0; n1 < 32; ++n1) {
-                        const float2 s = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
-                        d[32 * h + n1].x = fmaf(wgt, s.x, d[32 * h + n1].x);
-                        d[32 * h + n1].y = fmaf(wgt, s.y, d[32 * h + n1].y);
+                        const cpx s = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
+                        d[32 * h + n1] = pfma(mk(wgt, wgt), s, d[32 * h + n1]);
                     }
             }
         } else {
@@ -473,10 +475,6 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     // registers of the current one are dead (after the arg-max), so that its HBM
     // latency hides under the rest of the tail; `have` = d already holds trace b.
     bool have = false;
-#ifdef OFX_STAMPS
-    unsigned long long stamp_acc[16] = {0};
-    unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
-#endif
     for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
         float* row = out + (size_t)b * pd.row;
         if (valid && !valid[b]) {
@@ -526,7 +524,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     if (lo <= r0 && r0 + 1024 <= hi) {                    // uniform: full row
 #pragma unroll
                         for (int h = 0; h < VT; ++h) {
-                            const float2 v = d[32 * h + n1];
+                            const cpx v = d[32 * h + n1];
                             s += v.x + v.y;
                             sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
                             mx = fmaxf(mx, fmaxf(v.x, v.y));
@@ -538,7 +536,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                             const int n = r0 + 2 * (tl + FT * h);
                             const bool in0 = (n >= lo) && (n < hi);
                             const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
-                            const float2 v = d[32 * h + n1];
+                            const cpx v = d[32 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
                             s += y0 + y1;
                             sq = fmaf(y0, y0, fmaf(y1, y1, sq));
@@ -585,20 +583,30 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             continue;
         }
 
+#ifdef ABL_LOADONLY
+        {   // diagnostic: stream the traces and do nothing else
+            cpx acc = mk(0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) acc += d[j];
+            if (acc.x + acc.y == 1.2345f) row[0] = acc.x;
+            have = false;
+            continue;
+        }
+#endif
         STAMP(1);                                // wait for the trace + TD windows
         // ---------------------------------------------------------------- F1
         if constexpr (VT == 2) {
-            const T1Group g0 = t1_load(t1q, tl, 0);
-            const T1Group g1 = t1_load(t1q, tl + FT, 0);
+            const T1Anch g0 = t1_load(t1q, tl);
+            const T1Anch g1 = t1_load(t1q, tl + FT);
             __builtin_amdgcn_sched_barrier(0);         // keep the requests ahead of the DFTs
             dft<32, -1, NV, 0>(d);
             dft<32, -1, NV, 32 * (VT - 1)>(d);
-            t1_apply<false, 0>(d, t1q, tl, g0);
-            t1_apply<false, 32 * (VT - 1)>(d, t1q, tl + FT, g1);
+            t1_apply<false, 0>(d, g0);
+            t1_apply<false, 32 * (VT - 1)>(d, g1);
         } else {
             dft<32, -1, NV, 0>(d);
             __builtin_amdgcn_sched_barrier(0);         // 128-VGPR build: no early requests
-            t1_apply<false, 0>(d, t1q, tl, t1_load(t1q, tl, 0));
+            t1_apply<false, 0>(d, t1_load(t1q, tl));
         }
         STAMP(2);                                // F1
         if constexpr (DIAG_D1) {
@@ -623,30 +631,34 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                  HB2);
         STAMP(5);                                // E2
         // ------------------------------------------- F3, middle, I3 (registers)
-        float chi0p = 0.0f;
+        cpx chi2v = mk(0.0f, 0.0f);
         constexpr bool STAGE_B = (VT == 1) && SPLIT_EXCHANGE;
         if constexpr (STAGE_B) {
             dft<16, -1, NV, 0>(d);
             dft<16, -1, NV, 16>(d);
-            const float2 a8 = d[8];
-            if (wave == 0) perm_in<0>(d, tl == 0);
-            float2* xs = reinterpret_cast<float2*>(L.xb) + tl;
+            const cpx a8 = d[8];
+            if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
+            cpx* xs = reinterpret_cast<cpx*>(L.xb) + tl;
+            const cpx tb = buf_ld2(rtb, tl * 8, 0);
+            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
             __syncthreads();                   // every E2 read is done: the buffer is free
 #pragma unroll
             for (int j = 0; j < 16; ++j) xs[j * FT] = d[16 + j];
-            chi0p += middle_slots_staged<0>(d, rmid, tl, L, xs);
+            chi2v = middle_slots_staged<0>(d, rmid, tl, L, xs, tb, tbh, chi2v);
 #pragma unroll
             for (int j = 0; j < 16; ++j) d[16 + j] = xs[j * FT];
-            if (wave == 0) chi0p = perm_out<0>(d, tl == 0, a8, tabs, chi0p);
+            if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, tabs, chi2v, L.perm);
             dft<16, +1, NV, 0>(d);
             dft<16, +1, NV, 16>(d);
         } else {
             dft<16, -1, NV, 0>(d);
             dft<16, -1, NV, 16>(d);
-            const float2 a8 = d[8];
-            if (wave == 0) perm_in<0>(d, tl == 0);
-            chi0p += middle_slots<0>(d, rmid, tl, L);
-            if (wave == 0) chi0p = perm_out<0>(d, tl == 0, a8, tabs, chi0p);
+            const cpx a8 = d[8];
+            if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
+            const cpx tb = buf_ld2(rtb, tl * 8, 0);
+            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
+            chi2v = middle_slots<0>(d, rmid, tl, L, tb, tbh, chi2v);
+            if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, tabs, chi2v, L.perm);
             dft<16, +1, NV, 0>(d);
             dft<16, +1, NV, 16>(d);
         }
@@ -654,10 +666,12 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             constexpr int O = 32 * (VT - 1);
             dft<16, -1, NV, O>(d);
             dft<16, -1, NV, O + 16>(d);
-            chi0p += middle_slots<O>(d, rmid, tl + FT, L);
+            const cpx tb = buf_ld2(rtb, (tl + FT) * 8, 0);
+            chi2v = middle_slots<O>(d, rmid, tl + FT, L, tb, tb, chi2v);
             dft<16, +1, NV, O>(d);
             dft<16, +1, NV, O + 16>(d);
         }
+        const float chi0p = chi2v.x + chi2v.y;
         STAMP(6);                                // F3 + middle + I3
         int tl2 = tid;
         asm volatile("" : "+v"(tl2));          // no CSE of addresses across the middle
@@ -677,15 +691,15 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
         STAMP(8);                                // I2
         {
-            T1Group g0, g1;
+            T1Anch g0, g1;
             if constexpr (!DIAG_D1) {                  // requests ahead of the exchange
-                g0 = t1_load(t1q, tl2, 0);
-                g1 = t1_load(t1q, tl2 + FT, 0);
+                g0 = t1_load(t1q, tl2);
+                g1 = t1_load(t1q, tl2 + FT);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (DIAG_D1) {
                 exchange_d1(Q0, true);
-                g0 = t1_load(t1q, tl2, 0);
+                g0 = t1_load(t1q, tl2);
                 g1 = g0;
             } else {
                 exchange([&](int h, int j) { return QQ(h).e1r(j); }, [](int h, int) { return h; },
@@ -694,8 +708,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
             STAMP(9);                            // E4
             // ------------------------------------------------------------ I1
-            t1_apply<true, 0>(d, t1q, tl2, g0);
-            if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, t1q, tl2 + FT, g1);
+            t1_apply<true, 0>(d, g0);
+            if constexpr (VT == 2) t1_apply<true, 32 * (VT - 1)>(d, g1);
         }
         dft<32, +1, NV, 0>(d);
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
@@ -728,14 +742,16 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         for (int g = 0; g < NG; ++g) {
             float m = 0.0f;
 #pragma unroll
-            for (int j = 8 * g; j < 8 * g + 8; ++j)
-                m = fmaxf(m, fmaxf(d[j].x * d[j].x, d[j].y * d[j].y));
+            for (int j = 8 * g; j < 8 * g + 8; ++j) {
+                const cpx sq = d[j] * d[j];
+                m = fmaxf(m, fmaxf(sq.x, sq.y));
+            }
             gm[g] = m;
             mloc = fmaxf(mloc, m);
         }
         // low-frequency chi2 tables for this thread's bins: requested now, used at the end
         constexpr int NLK = (NLOW_MAX + FT - 1) / FT;
-        float2 lk_s[NLK];
+        cpx lk_s[NLK];
         float lk_g[NLK];
 #pragma unroll
         for (int i = 0; i < NLK; ++i) {
@@ -782,7 +798,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 #pragma unroll
                     for (int j = 8 * g; j < 8 * g + 8; ++j) {
                         const int n1 = j & 31;
-                        const float2 v = d[j];
+                        const cpx v = d[j];
                         const int i0 = (base + 1024 * n1) & (FN - 1);
                         const int i1 = (base + 1024 * n1 + 1) & (FN - 1);
                         if (v.x * v.x == Mstar && i0 < fullbest.idx) {
@@ -811,7 +827,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         if constexpr (SPLIT_EXCHANGE) {
                             L.xb[m] = e ? d[32 * h + n1].y : d[32 * h + n1].x;   // A(2m+e)
                         } else {
-                            reinterpret_cast<float2*>(L.xb)[m] = d[32 * h + n1]; // A(2m), A(2m+1)
+                            reinterpret_cast<cpx*>(L.xb)[m] = d[32 * h + n1];    // A(2m), A(2m+1)
                         }
                     }
                 __syncthreads();
@@ -850,7 +866,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
                 float acc = 0.0f;
                 for (int k = lo + lane_t; k < hi; k += 64) {
-                    const float2 x2 = L.xlow[k];
+                    const cpx x2 = L.xlow[k];
                     acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
                 }
                 acc = ofx_wave_sum(acc);
@@ -881,10 +897,10 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             for (int i = 0; i < NLK; ++i) {
                 const int k = tt + FT * i;
                 if (k < sq.nlow) {
-                    const float2 x2 = L.xlow[k];
+                    const cpx x2 = L.xlow[k];
                     low += ofx_lowchi2_term(k, FN, dl, best.amp,
-                                            make_float2(0.5f * x2.x, 0.5f * x2.y), lk_s[i],
-                                            lk_g[i]);
+                                            make_float2(0.5f * x2.x, 0.5f * x2.y),
+                                            make_float2(lk_s[i].x, lk_s[i].y), lk_g[i]);
                 }
             }
             low = ofx_wave_sum(low);
@@ -910,10 +926,6 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
         STAMP(12);                               // tail B: lowchi2 + row write
     }
-#ifdef OFX_STAMPS
-    if (tid == 0 && tabs.dbg)
-        for (int i = 0; i < 16; ++i) tabs.dbg[blockIdx.x * 16 + i] = stamp_acc[i];
-#endif
 }
 
 }  // namespace
@@ -931,13 +943,14 @@ int ofx_fused_release(ofx_plan* p) {
 static int fused_tables(ofx_plan* p) {
     if (p->d_tw1) return OFX_OK;
     const double PI2 = 6.283185307179586476925286766559;
-    std::vector<float2> t1(32 * 512), t2(32 * 16);
-    for (int k1 = 0; k1 < 32; ++k1)
+    std::vector<float2> t1(10 * 512), t2(32 * 16 + FV);
+    const int anchor_mult[10] = {1, 2, 3, 4, 5, 6, 7, 8, 16, 24};    // B1..B7, A1..A3
+    for (int i = 0; i < 10; ++i)
         for (int n = 0; n < 512; ++n) {
-            const long long e = ((long long)k1 * n) % FM;
+            const long long e = ((long long)anchor_mult[i] * n) % FM;
             const double a = -PI2 * (double)e / FM;
-            // packed as float4 rows: t1q[k1/2][n] = (w^{k1 even}, w^{k1 odd})
-            t1[((k1 >> 1) * 512 + n) * 2 + (k1 & 1)] =
+            // float4 rows: t1a[i/2][n] = (anchor i even, anchor i odd)
+            t1[((i >> 1) * 512 + n) * 2 + (i & 1)] =
                 make_float2((float)std::cos(a), (float)std::sin(a));
         }
     for (int k2 = 0; k2 < 32; ++k2)
@@ -946,6 +959,10 @@ static int fused_tables(ofx_plan* p) {
             const double a = -PI2 * (double)e / 512.0;
             t2[k2 * 16 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
+    for (int v = 0; v < FV; ++v) {      // tbase[v] = i exp(-2 pi i v / N), stored after t2
+        const double a = -PI2 * (double)v / FN;
+        t2[32 * 16 + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
+    }
     OFX_HIP(hipMalloc(&p->d_tw1, sizeof(float2) * t1.size()));
     OFX_HIP(hipMalloc(&p->d_tw2, sizeof(float2) * t2.size()));
     OFX_HIP(hipMemcpy(p->d_tw1, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
@@ -954,16 +971,19 @@ static int fused_tables(ofx_plan* p) {
 }
 
 // Build the middle-step tables of one slot from the fp64 one-sided filter.
-//   d_pq layout: [0 .. 16*512)        midA (t_k, W_k/2)
-//                [16*512 .. 2*16*512) midB (conj(W_p)/2, g_k', g_p')
-//                [2*16*512]           (W_{M/2}.x, W_{M/2}.y, g_{M/2}, 0)
+//   d_pq layout (float4 units): [0 .. 16*512)   midW  (W_k / 2, conj(W_p) / 2)   [slot j][v]
+//                               [16*512 .. +8*512) midG (g_k', g_p') as float2   [slot j][v]
+//                               last entry       (W_{M/2}.x, W_{M/2}.y, g_{M/2}, 0)
+// Slot j of virtual thread v pairs bin k = v + 1024 j with p = M - k (v = 0: k = 1024 j for
+// j < 8 and 512 + 1024 (j - 8) above; k = 0 pairs DC with Nyquist).
 int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
     int rc = fused_tables(p);
     if (rc) return rc;
     OfxSlotHost& h = p->slot[slot];
-    const double PI2 = 6.283185307179586476925286766559;
     const std::vector<double>& g = h.g_host;
-    std::vector<float4> tab(2 * 16 * FV + 1);
+    constexpr int NW = 16 * FV, NG = 8 * FV;
+    std::vector<float4> tab(NW + NG + 1);
+    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
     auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
     for (int v = 0; v < FV; ++v) {
         for (int j = 0; j < 16; ++j) {
@@ -984,18 +1004,16 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
                 gk = g[k] / 2.0;
                 gp = g[pidx] / 2.0;
             }
-            const double a = -PI2 * (double)k / FN;
-            tab[j * FV + v] = make_float4((float)std::cos(a), (float)std::sin(a),
-                                          (float)(wkr / 2.0), (float)(wki / 2.0));
-            tab[16 * FV + j * FV + v] =
-                make_float4((float)(wpr / 2.0), (float)(-wpi / 2.0), (float)gk, (float)gp);
+            tab[j * FV + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0),
+                                          (float)(wpr / 2.0), (float)(-wpi / 2.0));
+            tg[j * FV + v] = make_float2((float)gk, (float)gp);
         }
     }
-    tab[2 * 16 * FV] = make_float4((float)wf[2 * (FM / 2)], (float)wf[2 * (FM / 2) + 1],
-                                   (float)g[FM / 2], 0.0f);
-    h.wq_x = tab[2 * 16 * FV].x;
-    h.wq_y = tab[2 * 16 * FV].y;
-    h.gq = tab[2 * 16 * FV].z;
+    tab[NW + NG] = make_float4((float)wf[2 * (FM / 2)], (float)wf[2 * (FM / 2) + 1],
+                               (float)g[FM / 2], 0.0f);
+    h.wq_x = tab[NW + NG].x;
+    h.wq_y = tab[NW + NG].y;
+    h.gq = tab[NW + NG].z;
     OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
     OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
     return OFX_OK;
@@ -1013,47 +1031,26 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
         attr_set = true;
     }
     long long grid = (long long)p->cu_count * WG_PER_CU;
-#ifdef OFX_STAMPS
-    if (const char* e = getenv("OFX_DIAG_WGPC")) grid = (long long)p->cu_count * atoi(e);
-#endif
+    size_t lds_bytes = sizeof(FusedLds);
+    // diagnostic: OFX_DIAG_WGPC=1 runs one workgroup per CU (uncontended phase times)
+    static const int diag_wgpc = getenv("OFX_DIAG_WGPC") ? atoi(getenv("OFX_DIAG_WGPC")) : 0;
+    if (diag_wgpc == 1) {
+        grid = p->cu_count;
+        lds_bytes = 100 * 1024;
+        static bool attr2 = false;
+        if (!attr2) {
+            OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes));
+            attr2 = true;
+        }
+    }
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-#ifdef OFX_STAMPS
-    static unsigned long long* d_dbg = nullptr;
-    if (!d_dbg) (void)hipMalloc(&d_dbg, sizeof(unsigned long long) * 16 * 4096);
-    (void)hipMemsetAsync(d_dbg, 0, sizeof(unsigned long long) * 16 * 4096, st);
-    FusedTabs tabs2 = tabs;
-    tabs2.dbg = d_dbg;
-    size_t lds_bytes = sizeof(FusedLds);
-    if (getenv("OFX_DIAG_WGPC") && atoi(getenv("OFX_DIAG_WGPC")) == 1) {
-        lds_bytes = 100 * 1024;   // forces one workgroup per CU
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    }
     hipLaunchKernelGGL(k_fused<FEAT>, dim3((unsigned)grid), dim3(FT), lds_bytes, st, pd,
-                       sd, tabs2, d_traces, d_valid, n, d_out);
-    {
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h(16 * grid);
-        (void)hipMemcpy(h.data(), d_dbg, sizeof(unsigned long long) * 16 * grid,
-                        hipMemcpyDeviceToHost);
-        double tot[16] = {0};
-        for (long long b = 0; b < grid; ++b)
-            for (int i = 0; i < 16; ++i) tot[i] += (double)h[b * 16 + i];
-        const double per = (double)n;   // cycles per trace (summed over WGs / traces)
-        fprintf(stderr, "[stamps] cycles per trace per WG:");
-        const char* nm[13] = {"loop", "load+td", "F1", "E1", "F2", "E2", "mid", "E3", "I2",
-                              "E4", "I1", "tailA", "tailB"};
-        double sum = 0;
-        for (int i = 0; i < 13; ++i) { fprintf(stderr, " %s=%.0f", nm[i], tot[i] / per); sum += tot[i] / per; }
-        fprintf(stderr, " | total=%.0f\n", sum);
-    }
-#else
-    hipLaunchKernelGGL(k_fused<FEAT>, dim3((unsigned)grid), dim3(FT), sizeof(FusedLds), st, pd,
                        sd, tabs, d_traces, d_valid, n, d_out);
-#endif
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
@@ -1081,8 +1078,8 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             if (rc) return rc;
             tabs.t1 = p->d_tw1;
             tabs.t2 = p->d_tw2;
-            tabs.midA = p->slot[s].d_pq;
-            tabs.midB = p->slot[s].d_pq + 16 * FV;
+            tabs.midW = p->slot[s].d_pq;
+            tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * FV);
             tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
             tabs.gq = p->slot[s].gq;
         } else {
@@ -1090,6 +1087,13 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             if (rc) return rc;
             tabs.t1 = p->d_tw1;
             tabs.t2 = p->d_tw2;
+            tabs.midW = reinterpret_cast<const float4*>(p->d_tw1);   // never read: no searches
+            tabs.midG = p->d_tw1;
+        }
+        tabs.tbase = p->d_tw2 + 32 * 16;
+        {
+            const double a = -6.283185307179586476925286766559 * 512.0 / FN;
+            tabs.tb0hi = make_float2((float)-std::cos(a), (float)-std::sin(a));   // -t_512
         }
         // time-domain windows and bands ride on the first launch only
         OfxPlanDev pdl = pd;
