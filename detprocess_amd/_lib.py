@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("OFX_LIB", os.path.join(_HERE, "libofx.so"))
 OK = 0
 MEM_HOST, MEM_DEVICE = 0, 1
 ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT = 0, 1, 2
-SEARCH_NODELAY, SEARCH_DELAY = 0, 1
+SEARCH_NODELAY, SEARCH_DELAY, SEARCH_DELAY_INTERP = 0, 1, 2
 SEARCH_FLOATS, TDWIN_FLOATS, BAND_FLOATS = 8, 8, 1
 MAX_SLOTS, MAX_SEARCHES, MAX_TDWIN, MAX_TERMS, MAX_BANDS = 8, 8, 8, 8, 16
 COL = {"amp": 0, "t0": 1, "chi2": 2, "lowchi2": 3, "chi2nopulse": 4,

@@ -114,9 +114,8 @@ class FeatureExtractors:
         names = ("amp", "t0", "chi2", "lowchi2")
         if not of_base.is_signal_stored(channel):
             return {f"{n}_{feature_base_name}": SENTINEL for n in names}
-        if interpolate:
-            raise NotImplementedError("interpolate=True is not on the GPU path yet")
-        r = of_base.fit(channel, template_tag, "delay", lowchi2_fcutoff=lowchi2_fcutoff)
+        r = of_base.fit(channel, template_tag, "delay", lowchi2_fcutoff=lowchi2_fcutoff,
+                        interpolate=bool(interpolate))
         sq = of_base.squeeze(channel)
         return {f"{n}_{feature_base_name}": _maybe_scalar(r[n], sq) for n in names}
 
@@ -130,14 +129,12 @@ class FeatureExtractors:
         names = ("amp", "t0", "chi2", "lowchi2", "chi2nopulse", "ampres", "timeres")
         if not of_base.is_signal_stored(channel):
             return {f"{n}_{feature_base_name}": SENTINEL for n in names}
-        if interpolate:
-            raise NotImplementedError("interpolate=True is not on the GPU path yet")
         tab = of_base.tables(channel, template_tag)
         lo, hi = search_range(tab.n_samples, tab.pretrigger_samples, of_base.sample_rate(),
                               window_min_from_trig_usec, window_max_from_trig_usec,
                               window_min_index, window_max_index, window_policy)
         r = of_base.fit(channel, template_tag, "delay", lo, hi, lgc_outside_window,
-                        lowchi2_fcutoff)
+                        lowchi2_fcutoff, bool(interpolate))
         sq = of_base.squeeze(channel)
         return {f"{n}_{feature_base_name}": _maybe_scalar(r[n], sq) for n in names}
 

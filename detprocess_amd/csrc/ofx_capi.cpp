@@ -114,8 +114,10 @@ extern "C" int ofx_plan_create(ofx_plan** out, int n_samples, int n_pretrigger,
     p->max_batch = max_batch;
     p->device = device;
     p->cu_count = prop.multiProcessorCount;
-    if (engine == OFX_ENGINE_AUTO)
+    if (engine == OFX_ENGINE_AUTO) {
+        p->engine_auto = true;
         engine = ofx_fused_supported(n_samples) ? OFX_ENGINE_FUSED : OFX_ENGINE_ROCFFT;
+    }
     p->engine = engine;
     p->chan[0] = 0;
     p->weight[0] = 1.0;
@@ -219,7 +221,8 @@ extern "C" int ofx_plan_add_search(ofx_plan* p, int slot, int kind, int lo, int 
         ofx_set_error("ofx_plan_add_search: slot %d has no filter", slot);
         return -OFX_ERR_STATE;
     }
-    if (kind != OFX_SEARCH_NODELAY && kind != OFX_SEARCH_DELAY) {
+    if (kind != OFX_SEARCH_NODELAY && kind != OFX_SEARCH_DELAY &&
+        kind != OFX_SEARCH_DELAY_INTERP) {
         ofx_set_error("ofx_plan_add_search: unknown kind %d", kind);
         return -OFX_ERR_ARG;
     }
@@ -231,6 +234,8 @@ extern "C" int ofx_plan_add_search(ofx_plan* p, int slot, int kind, int lo, int 
     }
     OfxSearchDev q;
     memset(&q, 0, sizeof(q));
+    q.interp = (kind == OFX_SEARCH_DELAY_INTERP) ? 1 : 0;
+    if (q.interp) kind = OFX_SEARCH_DELAY;
     q.kind = kind;
     if (kind == OFX_SEARCH_NODELAY) {
         q.lo = p->pre;
@@ -417,8 +422,12 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
     const size_t ev_floats = (size_t)p->n_channels * p->N;
 
     if (traces_mem == OFX_MEM_DEVICE && out_mem == OFX_MEM_DEVICE) {
-        if (p->engine == OFX_ENGINE_FUSED)
-            return ofx_fused_process(p, traces, valid, n, out, st);
+        if (p->engine == OFX_ENGINE_FUSED) {
+            const int rc = ofx_fused_process(p, traces, valid, n, out, st);
+            // AUTO: a plan the FUSED kernel cannot carry (lowchi2 cutoff or psd_amp band
+            // beyond its 512 stashed bins) runs on the general engine instead
+            if (rc != OFX_ERR_UNSUPPORTED || !p->engine_auto) return rc;
+        }
         return ofx_rocfft_process(p, traces, valid, n, out, st);
     }
 
@@ -451,6 +460,8 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
         int rc = (p->engine == OFX_ENGINE_FUSED)
                      ? ofx_fused_process(p, d_in, d_valid, nb, d_out, st)
                      : ofx_rocfft_process(p, d_in, d_valid, nb, d_out, st);
+        if (rc == OFX_ERR_UNSUPPORTED && p->engine == OFX_ENGINE_FUSED && p->engine_auto)
+            rc = ofx_rocfft_process(p, d_in, d_valid, nb, d_out, st);
         if (rc) return rc;
         if (out_mem == OFX_MEM_HOST) {
             OFX_HIP(hipMemcpyAsync(out + (size_t)b0 * row, d_out,

@@ -42,6 +42,7 @@ struct OfxSearchDev {
     int outside;   // search complement of [lo,hi)
     int nlow;      // one-sided bins k = 0..nlow-1 have |f_k| <= lowchi2_fcutoff
     int out_off;   // float offset of this search's record in the output row
+    int interp;    // OFX_SEARCH_DELAY_INTERP: refine around the discrete minimum
 };
 
 struct OfxSlotDev {
@@ -105,6 +106,7 @@ struct ofx_plan {
     int max_batch = 0;
     int device = 0;
     int engine = OFX_ENGINE_ROCFFT;
+    bool engine_auto = false;            // created with OFX_ENGINE_AUTO: may fall back per call
     int n_channels = 1, n_terms = 1;
     int chan[OFX_MAX_TERMS] = {0};
     double weight[OFX_MAX_TERMS] = {1.0};

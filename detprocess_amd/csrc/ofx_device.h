@@ -156,15 +156,24 @@ __device__ __forceinline__ float ofx_block_min(float v, float* scratch) {
 }
 
 // ------------------------------------------------------------ low-freq chi2
-// One term of  sum_{k < nlow} w_k g_k |V_k - A e^{-2 pi i k d / N} S_k|^2 ,
-// d = rolled index - pretrigger (integer lag), w_k = 1 at DC / Nyquist else 2
-// (one-sided evaluation of the two-sided sum; J symmetric, V and S Hermitian).
+// One term of  sum_{k < nlow} w_k g_k |V_k - A e^{-2 pi i k (d + frac) / N} S_k|^2 ,
+// d = rolled index - pretrigger (integer lag), frac = sub-sample refinement (0 unless the
+// search interpolates), w_k = 1 at DC / Nyquist else 2 (one-sided evaluation of the
+// two-sided sum; J symmetric, V and S Hermitian).  The integer part of the phase is
+// reduced exactly (k d mod N) before it becomes a float.
 __device__ __forceinline__ float ofx_lowchi2_term(int k, int N, int d, float amp,
-                                                  float2 V, float2 S, float g) {
-    long long m = ((long long)k * (long long)d) % (long long)N;
-    if (m < 0) m += N;
+                                                  float2 V, float2 S, float g,
+                                                  float frac = 0.0f) {
+    int m;
+    if ((N & (N - 1)) == 0) {
+        m = (int)(((unsigned)k * (unsigned)d) & (unsigned)(N - 1));   // wraps mod 2^32: exact
+    } else {
+        long long mm = ((long long)k * (long long)d) % (long long)N;
+        if (mm < 0) mm += N;
+        m = (int)mm;
+    }
     float sn, cs;
-    sincospif(-2.0f * (float)m / (float)N, &sn, &cs);
+    sincospif(-2.0f * ((float)m + (float)k * frac) / (float)N, &sn, &cs);
     // ph * S
     const float pr = cs * S.x - sn * S.y;
     const float pi = cs * S.y + sn * S.x;
@@ -174,16 +183,41 @@ __device__ __forceinline__ float ofx_lowchi2_term(int k, int N, int d, float amp
     return w * g * (rr * rr + ri * ri);
 }
 
+// interpolate=True: vertex of the parabola through chi2 at the rolled bins idx-1, idx,
+// idx+1 (chi2 = chi0 - A^2 norm) and the amplitude parabola evaluated at the same
+// offset (oracle/of1x1.py interpolate_of).  am / a0 / ap: amplitudes at idx-1 / idx /
+// idx+1.  No refinement at the array ends or when the three points are not convex.
+struct OfxRefined {
+    float amp, frac, chi2;
+};
+__device__ __forceinline__ OfxRefined ofx_interpolate(float am, float a0, float ap, int idx,
+                                                      int N, float norm, float chi0) {
+    OfxRefined r;
+    r.amp = a0;
+    r.frac = 0.0f;
+    r.chi2 = fmaf(-a0 * a0, norm, chi0);
+    if (idx <= 0 || idx >= N - 1) return r;
+    // y0 - y2 = norm (ap^2 - am^2);  y0 - 2 y1 + y2 = norm (2 a0^2 - am^2 - ap^2)
+    const float dpm = (ap - am) * (ap + am);
+    const float den = (a0 - am) * (a0 + am) + (a0 - ap) * (a0 + ap);
+    if (!(den * norm > 0.0f)) return r;
+    const float x = 0.5f * dpm / den;
+    r.frac = x;
+    r.chi2 = r.chi2 - 0.125f * norm * dpm * dpm / den;
+    r.amp = a0 + 0.5f * (ap - am) * x + 0.5f * ((am - a0) + (ap - a0)) * x * x;
+    return r;
+}
+
 // ----------------------------------------------------------- record writer
 __device__ __forceinline__ void ofx_write_search(float* row, const OfxSearchDev& q,
                                                  const OfxSlotDev& sd, float inv_fs,
                                                  int pre, float chi0, OfxCand best,
-                                                 float lowchi2) {
+                                                 float lowchi2, const OfxRefined* ref = nullptr) {
     float* o = row + q.out_off;
-    const float amp = best.amp;
+    const float amp = ref ? ref->amp : best.amp;
     o[OFX_COL_AMP] = amp;
-    o[OFX_COL_T0] = (float)(best.idx - pre) * inv_fs;
-    o[OFX_COL_CHI2] = fmaf(-amp * amp, sd.norm, chi0);
+    o[OFX_COL_T0] = ((float)(best.idx - pre) + (ref ? ref->frac : 0.0f)) * inv_fs;
+    o[OFX_COL_CHI2] = ref ? ref->chi2 : fmaf(-amp * amp, sd.norm, chi0);
     o[OFX_COL_LOWCHI2] = lowchi2;
     o[OFX_COL_CHI2NOPULSE] = chi0;
     o[OFX_COL_AMPRES] = sd.ampres;

@@ -74,6 +74,8 @@ struct FusedLds {
     float lowp[OFX_MAX_SEARCHES][NWAVE];    // low-frequency chi2 per wave
     float bcast[8];
     cpx perm[32];                           // virtual thread 0's permutation bounce buffer
+    float nb[OFX_MAX_SEARCHES][2];          // amplitudes next to the winner (interpolation)
+    OfxRefined ref[OFX_MAX_SEARCHES];       // refined fits
 };
 static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
 
@@ -310,7 +312,8 @@ struct Roles {
 };
 
 // ------------------------------------------------------------------ the kernel
-// FEAT bit 0: plan has searches that are not full-range (scan the LDS lag dump)
+// FEAT bit 0: plan has searches that are not full-range (scan the LDS lag dump) or that
+//             interpolate (neighbour amplitudes of the winner)
 // FEAT bit 1: plan has time-domain windows
 // FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
 template <int FEAT>
@@ -892,15 +895,38 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 else best = ofx_cand_none();
             }
             const int dl = best.idx - pre;
+            OfxRefined ref;
+            ref.amp = best.amp;
+            ref.frac = 0.0f;
+            ref.chi2 = 0.0f;
+            if constexpr (FEAT & 1) {
+                if (sq.interp) {           // uniform: amplitudes at the rolled bins idx -+ 1
+                    if (tt < 2) L.nb[q][tt] = 0.0f;
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        const int i0 = (2 * (tt + FT * (j / 32)) + pre + 1024 * (j & 31)) & (FN - 1);
+                        const int i1 = (i0 + 1) & (FN - 1);
+                        if (i0 == best.idx - 1) L.nb[q][0] = d[j].x;
+                        if (i1 == best.idx - 1) L.nb[q][0] = d[j].y;
+                        if (i0 == best.idx + 1) L.nb[q][1] = d[j].x;
+                        if (i1 == best.idx + 1) L.nb[q][1] = d[j].y;
+                    }
+                    __syncthreads();
+                    ref = ofx_interpolate(L.nb[q][0], best.amp, L.nb[q][1], best.idx, FN, sd.norm, chi0);
+                    if (tt == 0) L.ref[q] = ref;
+                }
+            }
             float low = 0.0f;
 #pragma unroll
             for (int i = 0; i < NLK; ++i) {
                 const int k = tt + FT * i;
                 if (k < sq.nlow) {
                     const cpx x2 = L.xlow[k];
-                    low += ofx_lowchi2_term(k, FN, dl, best.amp,
+                    low += ofx_lowchi2_term(k, FN, dl, ref.amp,
                                             make_float2(0.5f * x2.x, 0.5f * x2.y),
-                                            make_float2(lk_s[i].x, lk_s[i].y), lk_g[i]);
+                                            make_float2(lk_s[i].x, lk_s[i].y), lk_g[i],
+                                            ref.frac);
                 }
             }
             low = ofx_wave_sum(low);
@@ -921,7 +947,10 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             for (int q = 0; q < sd.n_search; ++q) {
                 float lw = 0.0f;
                 for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
-                ofx_write_search(row, sd.search[q], sd, pd.inv_fs, pre, chi0, L.fin[q], lw);
+                const OfxRefined* rp = nullptr;
+                if constexpr (FEAT & 1)
+                    if (sd.search[q].interp) rp = &L.ref[q];
+                ofx_write_search(row, sd.search[q], sd, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
             }
         }
         STAMP(12);                               // tail B: lowchi2 + row write
@@ -1118,7 +1147,7 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
         for (int q = 0; q < sd.n_search; ++q) {
             const OfxSearchDev& sq = sd.search[q];
             if (sq.kind == OFX_SEARCH_DELAY &&
-                !(sq.lo == 0 && sq.hi == p->N && !sq.outside))
+                (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
                 feat |= 1;
             if (sq.nlow > NLOW_MAX) {
                 ofx_set_error("FUSED engine: lowchi2_fcutoff covers %d bins (> %d)", sq.nlow,

@@ -164,12 +164,25 @@ __global__ __launch_bounds__(RB) void k_search(OfxPlanDev pd, OfxSlotDev sd,
         }
         best = ofx_cand_block_reduce(best, cscratch);
         const int d = best.idx - pre;
+        OfxRefined ref;
+        ref.amp = best.amp;
+        ref.frac = 0.0f;
+        if (sq.interp && best.idx > 0 && best.idx < N - 1) {
+            // every thread reads the same two neighbours (rolled bins idx -+ 1)
+            int nm = best.idx - 1 - pre, np = best.idx + 1 - pre;
+            if (nm < 0) nm += N;
+            if (np < 0) np += N;
+            ref = ofx_interpolate(a[nm], best.amp, a[np], best.idx, N, sd.norm, chi0);
+        } else if (sq.interp) {
+            ref = ofx_interpolate(0.f, best.amp, 0.f, best.idx, N, sd.norm, chi0);
+        }
         float low = 0.0f;
         for (int k = threadIdx.x; k < sq.nlow; k += RB)
-            low += ofx_lowchi2_term(k, N, d, best.amp, V[k], sd.s[k], sd.g[k]);
+            low += ofx_lowchi2_term(k, N, d, ref.amp, V[k], sd.s[k], sd.g[k], ref.frac);
         low = ofx_block_sum(low, scratch);
         if (threadIdx.x == 0)
-            ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, low);
+            ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, low,
+                             sq.interp ? &ref : nullptr);
     }
 }
 

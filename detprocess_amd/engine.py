@@ -60,8 +60,10 @@ class OFPlan:
         self.filters[int(slot)] = tables
 
     def add_search(self, slot, kind, lo=0, hi=None, outside=False,
-                   lowchi2_fcutoff=10000.0):
+                   lowchi2_fcutoff=10000.0, interpolate=False):
         kind_i = {"nodelay": _lib.SEARCH_NODELAY, "delay": _lib.SEARCH_DELAY}[kind]
+        if interpolate and kind == "delay":
+            kind_i = _lib.SEARCH_DELAY_INTERP
         if hi is None:
             hi = self.n_samples
         sid = self._lib.ofx_plan_add_search(self._h, int(slot), kind_i, int(lo),

@@ -215,19 +215,20 @@ class OFBase:
         return self._plans[key]
 
     def fit(self, channel, template_tag, kind, lo=0, hi=None, outside=False,
-            lowchi2_fcutoff=10000.0):
+            lowchi2_fcutoff=10000.0, interpolate=False):
         """Run one of1x1 fit on the stored batch; returns dict of float32 arrays [B]
         keyed by _lib.COL names."""
         if not self.is_signal_stored(channel):
             raise ValueError(f"ERROR: no signal stored for channel {channel}")
-        ck = (channel, template_tag, kind, lo, hi, bool(outside), float(lowchi2_fcutoff))
+        ck = (channel, template_tag, kind, lo, hi, bool(outside), float(lowchi2_fcutoff),
+              bool(interpolate))
         if ck in self._fit_cache:
             return self._fit_cache[ck]
         tab = self.tables(channel, template_tag)
         plan = self._plan(tab.pretrigger_samples)
         plan.reset()
         plan.set_filter(0, tab)
-        sid = plan.add_search(0, kind, lo, hi, outside, lowchi2_fcutoff)
+        sid = plan.add_search(0, kind, lo, hi, outside, lowchi2_fcutoff, interpolate)
         out = plan.process(self._signals[channel])
         if not isinstance(out, np.ndarray):
             out = out.cpu().numpy()

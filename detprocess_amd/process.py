@@ -121,8 +121,6 @@ class FeatureProcessing:
                     if "template_tag" not in params:
                         raise ValueError(f'ERROR: a "template_tag" in yaml file is required '
                                          f'for channel {channel}, algorithm "{algorithm}" !')
-                    if params.get("interpolate", False):
-                        raise NotImplementedError("interpolate: True is not on the GPU path")
                     csd_tag = params.get("csd_tag", "default")
                     coupling = params.get("coupling", "AC")
                     peaks = params.get("ignored_frequency_peaks")
@@ -206,6 +204,7 @@ class FeatureProcessing:
                     slot = slots[skey]
                     skind, qtys = OF_ALGORITHMS[base]
                     fcut = float(params.get("lowchi2_fcutoff", 10000))
+                    interp = bool(params.get("interpolate", False)) and skind == "delay"
                     if base == "of1x1_constrained":
                         lo, hi = search_range(n_samples, nb_pre_plan, self._fs,
                                               params.get("window_min_from_trig_usec"),
@@ -213,9 +212,10 @@ class FeatureProcessing:
                                               wmin, wmax, self._policy)
                         sid = plan.add_search(slot, "delay", lo, hi,
                                               bool(params.get("lgc_outside_window", False)),
-                                              fcut)
+                                              fcut, interp)
                     else:
-                        sid = plan.add_search(slot, skind, lowchi2_fcutoff=fcut)
+                        sid = plan.add_search(slot, skind, lowchi2_fcutoff=fcut,
+                                              interpolate=interp)
                     cols.append(("of", slot, sid, qtys, algorithm))
                 elif kind == "band":
                     rng, rnames = utils.cleanup_freq_ranges(params["f_lims"])

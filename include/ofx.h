@@ -43,7 +43,10 @@ enum { OFX_ENGINE_AUTO = 0, OFX_ENGINE_FUSED = 1, OFX_ENGINE_ROCFFT = 2 };
 /* search kinds (one per of1x1 algorithm instance) */
 enum {
     OFX_SEARCH_NODELAY = 0,   /* algorithms.py:277-350  of1x1_nodelay        */
-    OFX_SEARCH_DELAY = 1      /* algorithms.py:354-432 / 435-570             */
+    OFX_SEARCH_DELAY = 1,     /* algorithms.py:354-432 / 435-570             */
+    OFX_SEARCH_DELAY_INTERP = 2  /* same with interpolate=True (algorithms.py:357, 443):
+                                    3-point parabolic refinement of t0 / amp / chi2 around
+                                    the discrete minimum; lowchi2 at the refined (amp, t0) */
 };
 
 #define OFX_MAX_SLOTS 8       /* (template_tag, csd_tag) filters per plan     */

@@ -430,7 +430,7 @@ OF_COLUMNS = ("amp", "t0", "chi2", "lowchi2", "chi2nopulse", "ampres", "timeres"
 
 
 def process_events(filt, traces, mode="unconstrained", lowchi2_fcutoff=10000.0,
-                   **window_kwargs):
+                   interpolate=False, **window_kwargs):
     """Per-event loop; returns dict of float64 arrays [B] (+ 'index')."""
     traces = np.asarray(traces)
     B = traces.shape[0]
@@ -442,10 +442,11 @@ def process_events(filt, traces, mode="unconstrained", lowchi2_fcutoff=10000.0,
             r.update(t0=0.0, chi2nopulse=np.nan, ampres=filt.ampres,
                      timeres=np.nan, index=filt.pre)
         elif mode == "unconstrained":
-            r = of1x1_withdelay(filt, traces[b], lowchi2_fcutoff=lowchi2_fcutoff)
+            r = of1x1_withdelay(filt, traces[b], lowchi2_fcutoff=lowchi2_fcutoff,
+                                interpolate=interpolate)
         elif mode == "constrained":
             r = of1x1_withdelay(filt, traces[b], lowchi2_fcutoff=lowchi2_fcutoff,
-                                **window_kwargs)
+                                interpolate=interpolate, **window_kwargs)
         else:
             raise ValueError("unknown mode")
         for k in OF_COLUMNS:

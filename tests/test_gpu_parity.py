@@ -42,6 +42,60 @@ def test_unconstrained_vs_oracle(n, engine, B):
     check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, f"{n}/{engine}")
 
 
+@pytest.mark.parametrize("n,engine", [(32768, "fused"), (32768, "rocfft"), (4096, "rocfft")])
+def test_interpolate_vs_oracle(n, engine):
+    """interpolate=True (algorithms.py:357, 443): parabolic refinement around the discrete
+    minimum, next to a plain search in the same plan; the refined t0 stays within half a
+    bin of the discrete one."""
+    plan, ft, filt, tmpl, psd = _mk(n, engine=engine)
+    pre = n // 2
+    s1 = plan.add_search(0, "delay", interpolate=True)
+    s2 = plan.add_search(0, "delay", pre - 300, pre + 300, interpolate=True,
+                         lowchi2_fcutoff=19000.0)
+    s3 = plan.add_search(0, "delay")
+    s4 = plan.add_search(0, "delay", 0, 1, interpolate=True)      # winner at the array end
+    x, _, _ = synth.make_traces(23, tmpl, psd, FS, ft.ampres, seed=77, max_delay=n // 16)
+    x32 = x.astype(np.float32)
+    x64 = x32.astype(np.float64)
+    out = _run(plan, x32)
+    r1 = orc.process_events(filt, x64, "unconstrained", interpolate=True)
+    r2 = orc.process_events(filt, x64, "constrained", lowchi2_fcutoff=19000.0, interpolate=True,
+                            window_min_index=pre - 300, window_max_index=pre + 300)
+    r3 = orc.process_events(filt, x64, "unconstrained")
+    r4 = orc.process_events(filt, x64, "constrained", interpolate=True, window_min_index=0,
+                            window_max_index=1)
+    check_search(out, plan.search_offset(0, s1), r1, "", ft.ampres, FS, f"{engine}/interp",
+                 interpolated=True)
+    check_search(out, plan.search_offset(0, s2), r2, "", ft.ampres, FS, f"{engine}/interp-win",
+                 interpolated=True)
+    check_search(out, plan.search_offset(0, s3), r3, "", ft.ampres, FS, f"{engine}/plain")
+    check_search(out, plan.search_offset(0, s4), r4, "", ft.ampres, FS, f"{engine}/interp-edge",
+                 interpolated=True)
+    o1 = plan.search_offset(0, s1)
+    t_bin = (out[:, o1 + 7] - pre) / FS
+    assert np.all(np.abs(out[:, o1 + 1] - t_bin) <= 0.5 / FS * (1 + 1e-6))
+    assert np.any(np.abs(out[:, o1 + 1] - t_bin) > 1e-3 / FS)      # it did refine something
+    assert np.all(out[:, o1 + 2] <= out[:, plan.search_offset(0, s3) + 2] * (1 + 1e-6))
+
+
+def test_auto_engine_falls_back_for_wide_lowchi2():
+    """lowchi2_fcutoff = 50 kHz covers 1311 bins; the FUSED kernel stashes 512, so an
+    AUTO plan runs that call on the general engine (an explicit FUSED plan refuses)."""
+    from detprocess_amd import _lib
+    n = 32768
+    plan, ft, filt, tmpl, psd = _mk(n, engine="auto")
+    sid = plan.add_search(0, "delay", lowchi2_fcutoff=50000.0)
+    x, _, _ = synth.make_traces(7, tmpl, psd, FS, ft.ampres, seed=9)
+    x32 = x.astype(np.float32)
+    out = _run(plan, x32)
+    ref = orc.process_events(filt, x32.astype(np.float64), "unconstrained", lowchi2_fcutoff=50000.0)
+    check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, "auto/50kHz")
+    plan2, *_ = _mk(n, engine="fused")
+    plan2.add_search(0, "delay", lowchi2_fcutoff=50000.0)
+    with pytest.raises(_lib.OfxError):
+        _run(plan2, x32)
+
+
 @pytest.mark.parametrize("engine", ["fused", "rocfft"])
 def test_all_search_kinds_and_lowchi2_cutoffs(engine):
     n = 32768

@@ -34,6 +34,11 @@ Melange1pc1ch:
         run: True
         base_algorithm: of1x1_unconstrained
         template_tag: glitch
+    of1x1_interp:
+        run: True
+        base_algorithm: of1x1_unconstrained
+        template_tag: default
+        interpolate: True
     baseline:
         run: True
         window_min_from_start_usec: 0
@@ -218,6 +223,12 @@ def test_feature_extractors_static_methods():
     assert np.allclose(r["amp_of1x1_nodelay"], refn["amp"], rtol=2e-5, atol=1e-4 * filt.ampres)
     assert np.allclose(r["lowchi2_of1x1_nodelay"], refn["lowchi2"], rtol=2e-5, atol=1e-2)
     assert "t0_of1x1_nodelay" not in r                      # algorithms.py:344-348
+    # interpolate=True (algorithms.py:357): refined t0 within half a bin of the discrete one
+    ri = FE.of1x1_unconstrained("chanA", ob, template_tag="default", interpolate=True)
+    refi = orc.process_events(filt, x32.astype(np.float64), "unconstrained", interpolate=True)
+    assert np.allclose(ri["t0_of1x1_unconstrained"], refi["t0"], rtol=0, atol=1e-3 / FS)
+    assert np.allclose(ri["amp_of1x1_unconstrained"], refi["amp"], rtol=2e-5,
+                       atol=1e-4 * filt.ampres)
     # trace family
     tr = x32[1]
     assert FE.baseline(tr, 100, 5000)["baseline"] == pytest.approx(
@@ -270,6 +281,10 @@ def test_feature_processing_batch_driver(engine):
     rn = orc.process_events(filt, x, "nodelay", lowchi2_fcutoff=15000)
     assert np.allclose(df["lowchi2_of1x1_nodelay_Melange1pc1ch"][ok], rn["lowchi2"][ok],
                        rtol=2e-5, atol=2e-6 * r["chi2nopulse"][ok].max())
+    ri = orc.process_events(filt, x, "unconstrained", interpolate=True)
+    assert np.allclose(df["t0_of1x1_interp_Melange1pc1ch"][ok], ri["t0"][ok], rtol=0, atol=1e-3 / FS)
+    assert np.allclose(df["chi2_of1x1_interp_Melange1pc1ch"][ok], ri["chi2"][ok], rtol=2e-5,
+                       atol=2e-6 * r["chi2nopulse"][ok].max())
     rg = orc.process_events(filt_g, x, "unconstrained")
     assert np.allclose(df["amp_of1x1_glitch_Melange1pc1ch"][ok], rg["amp"][ok], rtol=2e-5,
                        atol=1e-4 * filt_g.ampres)
