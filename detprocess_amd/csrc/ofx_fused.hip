@@ -115,6 +115,16 @@ __device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int s
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
 __device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
 
@@ -527,11 +537,13 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     if (lo <= r0 && r0 + 1024 <= hi) {                    // uniform: full row
 #pragma unroll
                         for (int h = 0; h < VT; ++h) {
+                            // (dependent forms only: anything that is a function of d
+                            // alone would be hoisted out of the window loop and spilled)
                             const cpx v = d[32 * h + n1];
-                            s += v.x + v.y;
+                            s = (s + v.x) + v.y;
                             sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
-                            mx = fmaxf(mx, fmaxf(v.x, v.y));
-                            mn = fminf(mn, fminf(v.x, v.y));
+                            mx = max3f(mx, v.x, v.y);
+                            mn = min3f(mn, v.x, v.y);
                         }
                     } else {                                              // edge row
 #pragma unroll
@@ -541,10 +553,10 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                             const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
                             const cpx v = d[32 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
-                            s += y0 + y1;
+                            s = (s + y0) + y1;
                             sq = fmaf(y0, y0, fmaf(y1, y1, sq));
-                            mx = fmaxf(mx, fmaxf(in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY));
-                            mn = fminf(mn, fminf(in0 ? v.x : INFINITY, in1 ? v.y : INFINITY));
+                            mx = max3f(mx, in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY);
+                            mn = min3f(mn, in0 ? v.x : INFINITY, in1 ? v.y : INFINITY);
                         }
                     }
                 }
@@ -901,16 +913,19 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             ref.chi2 = 0.0f;
             if constexpr (FEAT & 1) {
                 if (sq.interp) {           // uniform: amplitudes at the rolled bins idx -+ 1
-                    if (tt < 2) L.nb[q][tt] = 0.0f;
-                    __syncthreads();
+                    // lag n = 1024 n1 + 2 vt + e sits in thread vt % FT, register
+                    // 32 (vt / FT) + n1, component e: only the owning thread looks
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) {
-                        const int i0 = (2 * (tt + FT * (j / 32)) + pre + 1024 * (j & 31)) & (FN - 1);
-                        const int i1 = (i0 + 1) & (FN - 1);
-                        if (i0 == best.idx - 1) L.nb[q][0] = d[j].x;
-                        if (i1 == best.idx - 1) L.nb[q][0] = d[j].y;
-                        if (i0 == best.idx + 1) L.nb[q][1] = d[j].x;
-                        if (i1 == best.idx + 1) L.nb[q][1] = d[j].y;
+                    for (int side = 0; side < 2; ++side) {
+                        const int n = (best.idx + (side ? 1 : -1) - pre) & (FN - 1);
+                        const int vt_n = (n & 1023) >> 1;
+                        if (tt == (vt_n & (FT - 1))) {
+                            const int jn = 32 * (vt_n / FT) + (n >> 10);
+                            cpx v = d[0];
+#pragma unroll
+                            for (int j = 1; j < NV; ++j) v = (j == jn) ? d[j] : v;
+                            L.nb[q][side] = (n & 1) ? v.y : v.x;
+                        }
                     }
                     __syncthreads();
                     ref = ofx_interpolate(L.nb[q][0], best.amp, L.nb[q][1], best.idx, FN, sd.norm, chi0);
