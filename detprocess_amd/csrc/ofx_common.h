@@ -132,6 +132,9 @@ struct ofx_plan {
     // fused engine tables
     float2* d_tw1 = nullptr;             // stage-1 inter-stage twiddles
     float2* d_tw2 = nullptr;
+    void* d_fused_slots = nullptr;       // FUSED multi-slot launches: slot table ...
+    void* d_fused_spec = nullptr;        // ... and per-workgroup spectrum scratch
+    size_t fused_spec_bytes = 0;
 
     // timing of the dominant kernel
     bool timing = false;

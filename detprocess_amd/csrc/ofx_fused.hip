@@ -94,6 +94,12 @@ struct FusedTabs {
     float gq;             // g_{M/2}
 };
 
+// One filter slot of a multi-slot launch (device array, read through scalar loads).
+struct FusedSlotArg {
+    OfxSlotDev sd;
+    FusedTabs tabs;
+};
+
 __device__ __forceinline__ int partner_block(int v) { return v == 0 ? 512 : 1024 - v; }
 
 // Buffer loads: descriptor in SGPRs, one 32-bit VGPR byte offset per lane, the
@@ -326,18 +332,24 @@ struct Roles {
 //             interpolate (neighbour amplitudes of the winner)
 // FEAT bit 1: plan has time-domain windows
 // FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
-template <int FEAT>
+// MULTI: several filter slots (template_tag x csd_tag) share the forward transform of a
+//        trace: the spectrum (state after F3) is parked in a per-workgroup scratch area
+//        (128 KiB, L2 / MALL resident) and every slot runs middle -> inverse -> tail on
+//        it.  Slots come from `slots[0 .. nslots)`; sd / tabs then only carry the shared
+//        twiddle tables.  Not MULTI: the one slot is (sd, tabs), as kernel arguments.
+template <int FEAT, bool MULTI>
 __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
                                                  const float* __restrict__ traces,
                                                  const uint8_t* __restrict__ valid,
-                                                 long long n_traces, float* __restrict__ out) {
+                                                 long long n_traces, float* __restrict__ out,
+                                                 const FusedSlotArg* __restrict__ slots,
+                                                 int nslots, float2* __restrict__ spec) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     FusedLds& L = *reinterpret_cast<FusedLds*>(smem_raw);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int pre = pd.pre;
     const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 5 * 512 * 16);
-    const MidRsrc rmid = {make_rsrc(tabs.midW, 16 * 512 * 16), make_rsrc(tabs.midG, 16 * 512 * 8)};
     const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 512 * 8);
 
     for (int i = tid; i < 512; i += FT) L.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     };
 
     // Trace load into the register file (virtual thread vt reads z[512 n1 + vt]).
-    auto load_trace = [&](long long bb) {
+    auto load_trace = [&](long long bb) __attribute__((always_inline)) {
         int tl = tid;
         asm volatile("" : "+v"(tl));
         const float* e = traces + (size_t)bb * ev_stride;
@@ -482,6 +494,27 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 for (int n1 = 0; n1 < 32; ++n1)
                     d[32 * h + n1] = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
         }
+    };
+
+    // MULTI: the spectrum of the current trace, [value j][thread] in this workgroup's area.
+    const __amdgpu_buffer_rsrc_t rspec =
+        make_rsrc(spec + (MULTI ? (size_t)blockIdx.x * NV * FT : 0), NV * FT * 8);
+    auto store_spec = [&]() __attribute__((always_inline)) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            u32x2 v;
+            v.x = __float_as_uint(d[j].x);
+            v.y = __float_as_uint(d[j].y);
+            __builtin_amdgcn_raw_buffer_store_b64(v, rspec, tl * 8, j * FT * 8, 0);
+        }
+    };
+    auto load_spec = [&]() __attribute__((always_inline)) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+#pragma unroll
+        for (int j = 0; j < NV; ++j) d[j] = buf_ld2(rspec, tl * 8, j * FT * 8);
     };
 
     // Software-pipelined trace load: the next trace is requested as soon as the
@@ -593,7 +626,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 o[OFX_TD_LAST] = last;
             }
         }
-        if (sd.n_search == 0) {
+        if ((MULTI ? nslots : sd.n_search) == 0) {
             have = false;
             continue;
         }
@@ -645,42 +678,66 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                  [&](int h, int j) { return RR(h).e2r(j); }, [](int, int j) { return j >> 4; },
                  HB2);
         STAMP(5);                                // E2
+        // Everything from here to the output row depends on the filter slot.  Not MULTI:
+        // one pass on the kernel-argument slot (the loop and the selections fold away).
+#define SDX (MULTI ? slots[slot_i].sd : sd)
+#define TBX (MULTI ? slots[slot_i].tabs : tabs)
+        if constexpr (MULTI) {
+            // F3 for every block, park the spectrum, then one pass per slot
+            dft<16, -1, NV, 0>(d);
+            dft<16, -1, NV, 16>(d);
+            if constexpr (VT == 2) {
+                dft<16, -1, NV, 32>(d);
+                dft<16, -1, NV, 48>(d);
+            }
+            store_spec();
+        }
+        const int slot_n = MULTI ? nslots : 1;
+        for (int slot_i = 0; slot_i < slot_n; ++slot_i) {
         // ------------------------------------------- F3, middle, I3 (registers)
+        const MidRsrc rmid = {make_rsrc(TBX.midW, 16 * 512 * 16),
+                              make_rsrc(TBX.midG, 16 * 512 * 8)};
         cpx chi2v = mk(0.0f, 0.0f);
         constexpr bool STAGE_B = (VT == 1) && SPLIT_EXCHANGE;
         if constexpr (STAGE_B) {
-            dft<16, -1, NV, 0>(d);
-            dft<16, -1, NV, 16>(d);
+            if constexpr (!MULTI) {
+                dft<16, -1, NV, 0>(d);
+                dft<16, -1, NV, 16>(d);
+            }
             const cpx a8 = d[8];
             if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
             cpx* xs = reinterpret_cast<cpx*>(L.xb) + tl;
             const cpx tb = buf_ld2(rtb, tl * 8, 0);
-            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
+            const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
             __syncthreads();                   // every E2 read is done: the buffer is free
 #pragma unroll
             for (int j = 0; j < 16; ++j) xs[j * FT] = d[16 + j];
             chi2v = middle_slots_staged<0>(d, rmid, tl, L, xs, tb, tbh, chi2v);
 #pragma unroll
             for (int j = 0; j < 16; ++j) d[16 + j] = xs[j * FT];
-            if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, tabs, chi2v, L.perm);
+            if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, TBX, chi2v, L.perm);
             dft<16, +1, NV, 0>(d);
             dft<16, +1, NV, 16>(d);
         } else {
-            dft<16, -1, NV, 0>(d);
-            dft<16, -1, NV, 16>(d);
+            if constexpr (!MULTI) {
+                dft<16, -1, NV, 0>(d);
+                dft<16, -1, NV, 16>(d);
+            }
             const cpx a8 = d[8];
             if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
             const cpx tb = buf_ld2(rtb, tl * 8, 0);
-            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
+            const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
             chi2v = middle_slots<0>(d, rmid, tl, L, tb, tbh, chi2v);
-            if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, tabs, chi2v, L.perm);
+            if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, TBX, chi2v, L.perm);
             dft<16, +1, NV, 0>(d);
             dft<16, +1, NV, 16>(d);
         }
         if constexpr (VT == 2) {
             constexpr int O = 32 * (VT - 1);
-            dft<16, -1, NV, O>(d);
-            dft<16, -1, NV, O + 16>(d);
+            if constexpr (!MULTI) {
+                dft<16, -1, NV, O>(d);
+                dft<16, -1, NV, O + 16>(d);
+            }
             const cpx tb = buf_ld2(rtb, (tl + FT) * 8, 0);
             chi2v = middle_slots<O>(d, rmid, tl + FT, L, tb, tb, chi2v);
             dft<16, +1, NV, O>(d);
@@ -746,8 +803,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         int tt = tid;
         asm volatile("" : "+v"(tt));
         const int lane_t = tt & 63, wave_t = tt >> 6;
-        const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, NLOW_MAX * 8);
-        const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, NLOW_MAX * 4);
+        const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(SDX.s, NLOW_MAX * 8);
+        const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(SDX.g, NLOW_MAX * 4);
         // max of A^2 per group of 8 register pairs (kept so that the thread holding the
         // global maximum only has to search one group), then per thread
         constexpr int NG = NV / 8;
@@ -797,8 +854,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         // smallest rolled index among their lags with A^2 == max
         OfxCand fullbest = ofx_cand_none();
         bool any_full = false;
-        for (int q = 0; q < sd.n_search; ++q) {
-            const OfxSearchDev& sq = sd.search[q];
+        for (int q = 0; q < SDX.n_search; ++q) {
+            const OfxSearchDev& sq = SDX.search[q];
             any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
                         sq.hi == FN;
         }
@@ -846,8 +903,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         }
                     }
                 __syncthreads();
-                for (int q = 0; q < sd.n_search; ++q) {
-                    const OfxSearchDev& sq = sd.search[q];
+                for (int q = 0; q < SDX.n_search; ++q) {
+                    const OfxSearchDev& sq = SDX.search[q];
                     const bool full = !sq.outside && sq.lo == 0 && sq.hi == FN;
                     if (sq.kind != OFX_SEARCH_DELAY || full) continue;
                     OfxCand c = ofx_cand_none();
@@ -875,7 +932,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
 
         // psd_amp bands from the stashed 2 X_k (k < NLOW_MAX); one wave per band
-        if (pd.n_bands > 0) {
+        if (pd.n_bands > 0 && slot_i == 0) {
             const float cpsd = 0.25f / ((float)FN * pd.fs);      // (2 X)^2 / 4 / (N fs)
             for (int i = wave_t; i < pd.n_bands; i += NWAVE) {
                 const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
@@ -891,8 +948,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 
         // Per search: resolve the fit and every thread's share of the low-frequency chi2
         // (the last consumers of VMEM-loaded values), parked per wave in LDS ...
-        for (int q = 0; q < sd.n_search; ++q) {
-            const OfxSearchDev& sq = sd.search[q];
+        for (int q = 0; q < SDX.n_search; ++q) {
+            const OfxSearchDev& sq = SDX.search[q];
             OfxCand best;
             const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
                               sq.hi == FN;
@@ -928,7 +985,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         }
                     }
                     __syncthreads();
-                    ref = ofx_interpolate(L.nb[q][0], best.amp, L.nb[q][1], best.idx, FN, sd.norm, chi0);
+                    ref = ofx_interpolate(L.nb[q][0], best.amp, L.nb[q][1], best.idx, FN, SDX.norm, chi0);
                     if (tt == 0) L.ref[q] = ref;
                 }
             }
@@ -952,22 +1009,27 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         // ... then d and every table value are dead: request the next trace.  Nothing
         // below waits on vector memory, so the HBM latency hides under the epilogue and
         // the first stages of the other workgroup.
-        {
+        if (MULTI && slot_i + 1 < slot_n) {
+            load_spec();                         // the spectrum again, for the next slot
+        } else {
             const long long bn = b + gridDim.x;
             have = (bn < n_traces) && !(valid && !valid[bn]);
             if (have) load_trace(bn);
         }
         __syncthreads();
         if (tt == 0) {
-            for (int q = 0; q < sd.n_search; ++q) {
+            for (int q = 0; q < SDX.n_search; ++q) {
                 float lw = 0.0f;
                 for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
                 const OfxRefined* rp = nullptr;
                 if constexpr (FEAT & 1)
-                    if (sd.search[q].interp) rp = &L.ref[q];
-                ofx_write_search(row, sd.search[q], sd, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
+                    if (SDX.search[q].interp) rp = &L.ref[q];
+                ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
             }
         }
+        }
+#undef SDX
+#undef TBX
         STAMP(12);                               // tail B: lowchi2 + row write
     }
 }
@@ -981,6 +1043,10 @@ int ofx_fused_release(ofx_plan* p) {
     if (p->d_tw1) (void)hipFree(p->d_tw1);
     if (p->d_tw2) (void)hipFree(p->d_tw2);
     p->d_tw1 = p->d_tw2 = nullptr;
+    if (p->d_fused_slots) (void)hipFree(p->d_fused_slots);
+    if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
+    p->d_fused_slots = p->d_fused_spec = nullptr;
+    p->fused_spec_bytes = 0;
     return OFX_OK;
 }
 
@@ -1063,13 +1129,13 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
     return OFX_OK;
 }
 
-template <int FEAT>
+template <int FEAT, bool MULTI>
 static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const FusedTabs& tabs,
                   const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
-                  hipStream_t st) {
+                  hipStream_t st, const FusedSlotArg* d_slots, int nslots) {
     static bool attr_set = false;
     if (!attr_set) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT>),
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT, MULTI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)sizeof(FusedLds)));
         attr_set = true;
@@ -1083,84 +1149,87 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
         lds_bytes = 100 * 1024;
         static bool attr2 = false;
         if (!attr2) {
-            OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT>),
+            OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT, MULTI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes));
             attr2 = true;
+        }
+    }
+    if (MULTI) {
+        // per-workgroup spectrum scratch (sized for the full grid, allocated once)
+        const size_t need = (size_t)p->cu_count * WG_PER_CU * NV * FT * sizeof(float2);
+        if (p->fused_spec_bytes < need) {
+            if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
+            p->d_fused_spec = nullptr;
+            p->fused_spec_bytes = 0;
+            OFX_HIP(hipMalloc(&p->d_fused_spec, need));
+            p->fused_spec_bytes = need;
         }
     }
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_fused<FEAT>, dim3((unsigned)grid), dim3(FT), lds_bytes, st, pd,
-                       sd, tabs, d_traces, d_valid, n, d_out);
+    hipLaunchKernelGGL((k_fused<FEAT, MULTI>), dim3((unsigned)grid), dim3(FT), lds_bytes, st, pd,
+                       sd, tabs, d_traces, d_valid, n, d_out, d_slots, nslots,
+                       reinterpret_cast<float2*>(p->d_fused_spec));
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
+template <bool MULTI>
+static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd,
+                       const FusedTabs& tabs, const float* d_traces, const uint8_t* d_valid,
+                       long long n, float* d_out, hipStream_t st, const FusedSlotArg* d_slots,
+                       int nslots) {
+    switch (feat) {
+        case 0: return launch<0, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        case 1: return launch<1, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        case 2: return launch<2, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        case 3: return launch<3, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        case 4: return launch<4, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        case 5: return launch<5, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        case 6: return launch<6, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+        default: return launch<7, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+    }
+}
+
+// One launch per call: a plan with several filter slots runs them all on the shared
+// forward transform (MULTI kernel); time-domain windows and bands ride along once.
 int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
                       float* d_out, hipStream_t st) {
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
-    int nslots = 0;
-    for (int s = 0; s < OFX_MAX_SLOTS; ++s)
-        if (p->slot[s].set && !p->slot[s].searches.empty()) ++nslots;
-    bool first = true;
-    for (int s = 0; s < OFX_MAX_SLOTS || first; ++s) {
-        OfxSlotDev sd;
-        memset(&sd, 0, sizeof(sd));
-        FusedTabs tabs;
-        memset(&tabs, 0, sizeof(tabs));
-        if (nslots > 0) {
-            if (s >= OFX_MAX_SLOTS) break;
-            if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
-            ofx_fill_slot_dev(p, s, &sd);
-            int rc = fused_tables(p);
-            if (rc) return rc;
-            tabs.t1 = p->d_tw1;
-            tabs.t2 = p->d_tw2;
-            tabs.midW = p->slot[s].d_pq;
-            tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * FV);
-            tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
-            tabs.gq = p->slot[s].gq;
-        } else {
-            int rc = fused_tables(p);
-            if (rc) return rc;
-            tabs.t1 = p->d_tw1;
-            tabs.t2 = p->d_tw2;
-            tabs.midW = reinterpret_cast<const float4*>(p->d_tw1);   // never read: no searches
-            tabs.midG = p->d_tw1;
-        }
-        tabs.tbase = p->d_tw2 + 32 * 16;
-        {
-            const double a = -6.283185307179586476925286766559 * 512.0 / FN;
-            tabs.tb0hi = make_float2((float)-std::cos(a), (float)-std::sin(a));   // -t_512
-        }
-        // time-domain windows and bands ride on the first launch only
-        OfxPlanDev pdl = pd;
-        if (!first) {
-            pdl.n_tdwin = 0;
-            pdl.n_bands = 0;
-        }
-        if (pdl.n_bands > 0) {
-            if (nslots == 0) {
-                ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
-                              "search on the plan (use the ROCFFT engine otherwise)");
-                return OFX_ERR_UNSUPPORTED;
-            }
-            for (int i = 0; i < pdl.n_bands; ++i)
-                if (pdl.band[i].k_hi > NLOW_MAX) {
-                    ofx_set_error("FUSED engine: band [%d,%d) exceeds the %d stashed bins",
-                                  pdl.band[i].k_lo, pdl.band[i].k_hi, NLOW_MAX);
-                    return OFX_ERR_UNSUPPORTED;
-                }
-        }
-        int feat = 0;
-        for (int q = 0; q < sd.n_search; ++q) {
-            const OfxSearchDev& sq = sd.search[q];
+    int rc = fused_tables(p);
+    if (rc) return rc;
+    FusedTabs common;
+    memset(&common, 0, sizeof(common));
+    common.t1 = p->d_tw1;
+    common.t2 = p->d_tw2;
+    common.tbase = p->d_tw2 + 32 * 16;
+    {
+        const double a = -6.283185307179586476925286766559 * 512.0 / FN;
+        common.tb0hi = make_float2((float)-std::cos(a), (float)-std::sin(a));   // -t_512
+    }
+    common.midW = reinterpret_cast<const float4*>(p->d_tw1);   // never read without searches
+    common.midG = p->d_tw1;
+
+    std::vector<FusedSlotArg> args;
+    int feat = 0;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
+        if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
+        FusedSlotArg a;
+        memset(&a, 0, sizeof(a));
+        ofx_fill_slot_dev(p, s, &a.sd);
+        a.tabs = common;
+        a.tabs.midW = p->slot[s].d_pq;
+        a.tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * FV);
+        a.tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
+        a.tabs.gq = p->slot[s].gq;
+        for (int q = 0; q < a.sd.n_search; ++q) {
+            const OfxSearchDev& sq = a.sd.search[q];
             if (sq.kind == OFX_SEARCH_DELAY &&
                 (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
                 feat |= 1;
@@ -1170,22 +1239,44 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
                 return OFX_ERR_UNSUPPORTED;
             }
         }
-        if (pdl.n_tdwin > 0) feat |= 2;
-        if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
-        int rc;
-        switch (feat) {
-            case 0: rc = launch<0>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            case 1: rc = launch<1>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            case 2: rc = launch<2>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            case 3: rc = launch<3>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            case 4: rc = launch<4>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            case 5: rc = launch<5>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            case 6: rc = launch<6>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-            default: rc = launch<7>(p, pdl, sd, tabs, d_traces, d_valid, n, d_out, st); break;
-        }
-        if (rc) return rc;
-        first = false;
-        if (nslots == 0) break;
+        args.push_back(a);
     }
-    return OFX_OK;
+    const int nslots = (int)args.size();
+    if (pd.n_bands > 0) {
+        if (nslots == 0) {
+            ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
+                          "search on the plan (use the ROCFFT engine otherwise)");
+            return OFX_ERR_UNSUPPORTED;
+        }
+        for (int i = 0; i < pd.n_bands; ++i)
+            if (pd.band[i].k_hi > NLOW_MAX) {
+                ofx_set_error("FUSED engine: band [%d,%d) exceeds the %d stashed bins",
+                              pd.band[i].k_lo, pd.band[i].k_hi, NLOW_MAX);
+                return OFX_ERR_UNSUPPORTED;
+            }
+    }
+    if (pd.n_tdwin > 0) feat |= 2;
+    if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
+
+    if (nslots <= 1) {
+        OfxSlotDev sd;
+        memset(&sd, 0, sizeof(sd));
+        FusedTabs tabs = common;
+        if (nslots == 1) {
+            sd = args[0].sd;
+            tabs = args[0].tabs;
+        }
+        return launch_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, nullptr,
+                                  nslots);
+    }
+    // several slots: upload the slot table (the copy from pageable memory is staged
+    // before the call returns, so the host vector may die with this frame)
+    const size_t bytes = sizeof(FusedSlotArg) * (size_t)nslots;
+    if (!p->d_fused_slots)
+        OFX_HIP(hipMalloc(&p->d_fused_slots, sizeof(FusedSlotArg) * OFX_MAX_SLOTS));
+    OFX_HIP(hipMemcpyAsync(p->d_fused_slots, args.data(), bytes, hipMemcpyHostToDevice, st));
+    OfxSlotDev sd0;
+    memset(&sd0, 0, sizeof(sd0));
+    return launch_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,
+                             reinterpret_cast<const FusedSlotArg*>(p->d_fused_slots), nslots);
 }

@@ -78,6 +78,49 @@ def test_interpolate_vs_oracle(n, engine):
     assert np.all(out[:, o1 + 2] <= out[:, plan.search_offset(0, s3) + 2] * (1 + 1e-6))
 
 
+@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+def test_three_template_slots_share_one_pass(engine):
+    """BASELINE configs[3] shape: three template tags (pulse / glitch / muon) on one plan.
+    The FUSED engine runs them in one launch on the shared forward transform; every slot
+    must equal both the oracle and a single-slot plan of its own."""
+    from detprocess_amd import OFPlan
+    n, pre = 32768, 16384
+    psd = synth.make_psd(n, FS)
+    kinds = ("pulse", "glitch", "muon")
+    tmpls = [synth.make_template(n, pre, FS, k) for k in kinds]
+    fts = [build_filter(t, psd, FS, pre) for t in tmpls]
+    filts = [orc.OFFilter(t, psd, FS, pre) for t in tmpls]
+    plan = OFPlan(n, pre, FS, max_batch=64, device=0, engine=engine)
+    ids = []
+    for s, ft in enumerate(fts):
+        plan.set_filter(s, ft)
+        ids.append((plan.add_search(s, "nodelay"), plan.add_search(s, "delay"),
+                    plan.add_search(s, "delay", 15884, 16884, interpolate=(s == 1))))
+    w = plan.add_tdwindow(100, 9000)
+    x, _, _ = synth.make_traces(21, tmpls[0], psd, FS, fts[0].ampres, seed=314)
+    x32 = x.astype(np.float32)
+    x64 = x32.astype(np.float64)
+    out = _run(plan, x32)
+    for s, (ft, filt) in enumerate(zip(fts, filts)):
+        r_nd = orc.process_events(filt, x64, "nodelay")
+        r_un = orc.process_events(filt, x64, "unconstrained")
+        r_co = orc.process_events(filt, x64, "constrained", window_min_index=15884,
+                                  window_max_index=16884, interpolate=(s == 1))
+        check_search(out, plan.search_offset(s, ids[s][0]), r_nd, "", ft.ampres, FS, f"{kinds[s]}/nodelay")
+        check_search(out, plan.search_offset(s, ids[s][1]), r_un, "", ft.ampres, FS, f"{kinds[s]}/delay")
+        check_search(out, plan.search_offset(s, ids[s][2]), r_co, "", ft.ampres, FS, f"{kinds[s]}/window",
+                     interpolated=(s == 1))
+        solo = OFPlan(n, pre, FS, max_batch=64, device=0, engine=engine)
+        solo.set_filter(0, ft)
+        solo.add_search(0, "nodelay"); solo.add_search(0, "delay")
+        solo.add_search(0, "delay", 15884, 16884, interpolate=(s == 1))
+        so = _run(solo, x32)
+        o0 = plan.search_offset(s, ids[s][0])
+        assert np.array_equal(out[:, o0:o0 + 24], so[:, :24]), f"slot {s} differs from its solo plan"
+    ow = plan.tdwindow_offset(w)
+    assert np.allclose(out[:, ow], orc.baseline(x64, 100, 9000), rtol=1e-4, atol=1e-6 * np.abs(x64).max())
+
+
 def test_auto_engine_falls_back_for_wide_lowchi2():
     """lowchi2_fcutoff = 50 kHz covers 1311 bins; the FUSED kernel stashes 512, so an
     AUTO plan runs that call on the general engine (an explicit FUSED plan refuses)."""
