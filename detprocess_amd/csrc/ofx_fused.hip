@@ -848,12 +848,16 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             Mstar = fmaxf(Mstar, L.red[0][q]);
             chi0 += L.red[1][q];
         }
-        const float a_lag0 = L.bcast[0];
+        float a_lag0 = L.bcast[0];
+        // one register each from here on (the sums would otherwise be sunk to their uses
+        // with every per-wave partial kept alive)
+        asm volatile("" : "+v"(Mstar), "+v"(chi0), "+v"(a_lag0));
 
         // full-range delay fit: the thread(s) holding the maximum resolve the
         // smallest rolled index among their lags with A^2 == max
         OfxCand fullbest = ofx_cand_none();
         bool any_full = false;
+#pragma unroll 1
         for (int q = 0; q < SDX.n_search; ++q) {
             const OfxSearchDev& sq = SDX.search[q];
             any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
@@ -903,6 +907,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         }
                     }
                 __syncthreads();
+#pragma unroll 1
                 for (int q = 0; q < SDX.n_search; ++q) {
                     const OfxSearchDev& sq = SDX.search[q];
                     const bool full = !sq.outside && sq.lo == 0 && sq.hi == FN;
@@ -948,6 +953,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 
         // Per search: resolve the fit and every thread's share of the low-frequency chi2
         // (the last consumers of VMEM-loaded values), parked per wave in LDS ...
+#pragma unroll 1
         for (int q = 0; q < SDX.n_search; ++q) {
             const OfxSearchDev& sq = SDX.search[q];
             OfxCand best;
@@ -1018,6 +1024,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         }
         __syncthreads();
         if (tt == 0) {
+#pragma unroll 1
             for (int q = 0; q < SDX.n_search; ++q) {
                 float lw = 0.0f;
                 for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
