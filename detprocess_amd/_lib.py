@@ -43,6 +43,8 @@ _SYMBOLS = [
     ("ofx_plan_tdwindow_offset", C.c_int, [_p, C.c_int]),
     ("ofx_plan_band_offset", C.c_int, [_p, C.c_int]),
     ("ofx_process", C.c_int, [_p, _p, _p, C.c_longlong, C.c_int, _p, C.c_int, _p]),
+    ("ofx_process_adc", C.c_int, [_p, _p, C.c_longlong, C.c_int, _p, C.c_longlong, _p, _p, _p,
+                                  C.c_int, _p]),
     ("ofx_synth_traces", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                    C.c_ulonglong, _p]),

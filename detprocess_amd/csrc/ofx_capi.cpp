@@ -153,6 +153,8 @@ extern "C" int ofx_plan_destroy(ofx_plan* p) {
     ofx_plan_reset(p);
     ofx_rocfft_release(p);
     ofx_fused_release(p);
+    if (p->d_adc) (void)hipFree(p->d_adc);
+    if (p->d_trig) (void)hipFree(p->d_trig);
     if (p->d_stage_in) (void)hipFree(p->d_stage_in);
     if (p->d_stage_valid) (void)hipFree(p->d_stage_valid);
     if (p->d_stage_out) (void)hipFree(p->d_stage_out);
@@ -446,7 +448,12 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
                                    hipMemcpyHostToDevice, st));
             d_in = p->d_stage_in;
             if (valid) {
-                if (!p->d_stage_valid) OFX_HIP(hipMalloc(&p->d_stage_valid, (size_t)chunk));
+                if (!p->d_stage_valid || p->stage_valid_elems < (size_t)chunk) {
+                    if (p->d_stage_valid) (void)hipFree(p->d_stage_valid);
+                    p->d_stage_valid = nullptr;
+                    OFX_HIP(hipMalloc(&p->d_stage_valid, (size_t)chunk));
+                    p->stage_valid_elems = (size_t)chunk;
+                }
                 OFX_HIP(hipMemcpyAsync(p->d_stage_valid, valid + b0, (size_t)nb,
                                        hipMemcpyHostToDevice, st));
                 d_valid = p->d_stage_valid;
@@ -469,6 +476,89 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
                                    hipMemcpyDeviceToHost, st));
         }
         OFX_HIP(hipStreamSynchronize(st));
+    }
+    return OFX_OK;
+}
+
+// ------------------------------------------------------------ process (ADC)
+extern "C" int ofx_process_adc(ofx_plan* p, const int16_t* adc, long long n_stream, int adc_mem,
+                               const long long* trigger_index, long long n, const double* scale,
+                               const double* offset, float* out, int out_mem, void* stream) {
+    if (!p || n < 0 || n_stream < 0 || (n > 0 && (!adc || !trigger_index || !out)) || !scale ||
+        !offset) {
+        ofx_set_error("ofx_process_adc: bad argument");
+        return OFX_ERR_ARG;
+    }
+    const int row = ofx_row_floats(p);
+    if (row == 0) {
+        ofx_set_error("ofx_process_adc: plan has no searches, time-domain windows or bands");
+        return OFX_ERR_STATE;
+    }
+    if (n == 0) return OFX_OK;
+    OFX_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int C = p->n_channels;
+    const size_t ev_floats = (size_t)C * p->N;
+
+    // the stream(s): staged once, whatever the number of windows
+    const int16_t* d_adc = adc;
+    if (adc_mem == OFX_MEM_HOST) {
+        const size_t want = (size_t)C * (size_t)n_stream;
+        if (p->adc_elems < want) {
+            if (p->d_adc) (void)hipFree(p->d_adc);
+            p->d_adc = nullptr;
+            p->adc_elems = 0;
+            OFX_HIP(hipMalloc(&p->d_adc, want * sizeof(int16_t)));
+            p->adc_elems = want;
+        }
+        OFX_HIP(hipMemcpyAsync(p->d_adc, adc, want * sizeof(int16_t), hipMemcpyHostToDevice, st));
+        d_adc = p->d_adc;
+    }
+    if (p->trig_elems < (size_t)n) {
+        if (p->d_trig) (void)hipFree(p->d_trig);
+        p->d_trig = nullptr;
+        p->trig_elems = 0;
+        OFX_HIP(hipMalloc(&p->d_trig, (size_t)n * sizeof(long long)));
+        p->trig_elems = (size_t)n;
+    }
+    OFX_HIP(hipMemcpyAsync(p->d_trig, trigger_index, (size_t)n * sizeof(long long),
+                           hipMemcpyHostToDevice, st));
+    std::vector<float> sc(C), of(C);
+    for (int c = 0; c < C; ++c) {
+        sc[c] = (float)scale[c];
+        of[c] = (float)offset[c];
+    }
+
+    long long chunk = p->max_batch;
+    if (chunk > 32768) chunk = 32768;
+    int rc = ensure(&p->d_stage_in, &p->stage_in_floats, (size_t)chunk * ev_floats);
+    if (rc) return rc;
+    if (!p->d_stage_valid || p->stage_valid_elems < (size_t)chunk) {
+        if (p->d_stage_valid) (void)hipFree(p->d_stage_valid);
+        p->d_stage_valid = nullptr;
+        OFX_HIP(hipMalloc(&p->d_stage_valid, (size_t)chunk));
+        p->stage_valid_elems = (size_t)chunk;
+    }
+    if (out_mem == OFX_MEM_HOST) {
+        rc = ensure(&p->d_stage_out, &p->stage_out_floats, (size_t)chunk * row);
+        if (rc) return rc;
+    }
+    for (long long b0 = 0; b0 < n; b0 += chunk) {
+        const long long nb = (n - b0 < chunk) ? (n - b0) : chunk;
+        rc = ofx_cut_launch(d_adc, n_stream, C, p->N, p->pre, p->d_trig + b0, nb, sc.data(),
+                            of.data(), p->d_stage_in, p->d_stage_valid, st);
+        if (rc) return rc;
+        float* d_out = (out_mem == OFX_MEM_HOST) ? p->d_stage_out : out + (size_t)b0 * row;
+        rc = (p->engine == OFX_ENGINE_FUSED)
+                 ? ofx_fused_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st)
+                 : ofx_rocfft_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st);
+        if (rc == OFX_ERR_UNSUPPORTED && p->engine == OFX_ENGINE_FUSED && p->engine_auto)
+            rc = ofx_rocfft_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st);
+        if (rc) return rc;
+        if (out_mem == OFX_MEM_HOST)
+            OFX_HIP(hipMemcpyAsync(out + (size_t)b0 * row, d_out, (size_t)nb * row * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+        OFX_HIP(hipStreamSynchronize(st));      // the staging buffers are reused by the next chunk
     }
     return OFX_OK;
 }

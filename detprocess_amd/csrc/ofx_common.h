@@ -126,12 +126,17 @@ struct ofx_plan {
     float* d_stage_in = nullptr;
     size_t stage_in_floats = 0;
     uint8_t* d_stage_valid = nullptr;
+    size_t stage_valid_elems = 0;
     float* d_stage_out = nullptr;
     size_t stage_out_floats = 0;
 
     // fused engine tables
     float2* d_tw1 = nullptr;             // stage-1 inter-stage twiddles
     float2* d_tw2 = nullptr;
+    int16_t* d_adc = nullptr;            // ofx_process_adc: staged stream, trigger indices
+    size_t adc_elems = 0;
+    long long* d_trig = nullptr;
+    size_t trig_elems = 0;
     void* d_fused_slots = nullptr;       // FUSED multi-slot launches: slot table ...
     void* d_fused_spec = nullptr;        // ... and per-workgroup spectrum scratch
     size_t fused_spec_bytes = 0;
@@ -161,3 +166,8 @@ int ofx_fused_release(ofx_plan* p);
 // timing helpers
 int ofx_time_begin(ofx_plan* p, hipStream_t st, size_t* idx);
 int ofx_time_end(ofx_plan* p, hipStream_t st, size_t idx);
+
+// ofx_ingest.hip: windows of int16 streams -> float32 [nb, C, N] events + valid mask
+int ofx_cut_launch(const int16_t* d_adc, long long n_stream, int n_channels, int n_samples,
+                   int n_pretrigger, const long long* d_trig, long long nb, const float* scale,
+                   const float* offset, float* d_events, uint8_t* d_valid, hipStream_t st);

@@ -177,6 +177,54 @@ class OFPlan:
                    "ofx_process")
         return out
 
+    def process_adc(self, adc, trigger_index, scale, offset):
+        """Cut events out of continuous raw-data streams and run the hot path on them.
+
+        adc: int16 [C, n_stream] (C = the plan's channel count), a NumPy array or a CUDA
+        tensor; trigger_index: int64 [B] sample index of each trigger in the stream;
+        scale, offset: per channel, amps = float32(adc * scale) + offset (pytesio's
+        adctoamp conversion, coefficients from the file's detector_config).  Event b is
+        stream[:, trigger_index[b] - n_pretrigger : ... + n_samples]; a window that does not
+        fit gives a row of -999999.0 (processing_data.py:640-656).  Returns float32
+        [B, row_floats] of the same kind as ``adc``.
+        """
+        trig = np.ascontiguousarray(trigger_index, dtype=np.int64)
+        B = int(trig.shape[0])
+        sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64),
+                                                  (self.n_channels,)))
+        of = np.ascontiguousarray(np.broadcast_to(np.asarray(offset, dtype=np.float64),
+                                                  (self.n_channels,)))
+        row = self.row_floats
+        if isinstance(adc, np.ndarray):
+            a = np.ascontiguousarray(adc, dtype=np.int16)
+            if a.ndim == 1:
+                a = a[None, :]
+            if a.shape[0] != self.n_channels:
+                raise ValueError(f"ERROR: adc has {a.shape[0]} channels, plan expects "
+                                 f"{self.n_channels}")
+            out = np.empty((B, row), dtype=np.float32)
+            _lib.check(self._lib.ofx_process_adc(
+                self._h, a.ctypes.data, int(a.shape[1]), _lib.MEM_HOST, trig.ctypes.data, B,
+                sc.ctypes.data, of.ctypes.data, out.ctypes.data, _lib.MEM_HOST, None),
+                "ofx_process_adc")
+            return out
+        torch = _torch()
+        if not (isinstance(adc, torch.Tensor) and adc.is_cuda and adc.dtype == torch.int16):
+            raise TypeError("adc must be an int16 NumPy array or CUDA tensor")
+        a = adc.contiguous()
+        if a.dim() == 1:
+            a = a[None, :]
+        if a.shape[0] != self.n_channels:
+            raise ValueError(f"ERROR: adc has {a.shape[0]} channels, plan expects "
+                             f"{self.n_channels}")
+        out = torch.empty((B, row), dtype=torch.float32, device=a.device)
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _lib.check(self._lib.ofx_process_adc(
+            self._h, a.data_ptr(), int(a.shape[1]), _lib.MEM_DEVICE, trig.ctypes.data, B,
+            sc.ctypes.data, of.ctypes.data, out.data_ptr(), _lib.MEM_DEVICE,
+            C.c_void_p(stream)), "ofx_process_adc")
+        return out
+
     def _check_shape(self, shape):
         if len(shape) == 2:
             if self.n_channels != 1:

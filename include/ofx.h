@@ -178,6 +178,28 @@ int ofx_process(ofx_plan* plan, const float* traces, const uint8_t* valid,
                 void* stream);
 
 /*
+ * Cut-and-convert front end: the events of a dump are windows of continuous
+ * raw-data streams.  adc: int16 [n_channels, n_stream] (channel-major, the
+ * plan's n_channels), host or device memory; trigger_index: HOST int64
+ * [n_events], the sample index of each trigger in the stream.  Event b is
+ *   amps[c, j] = (float)adc[c, trigger_index[b] - n_pretrigger + j] * scale[c] + offset[c]
+ * for j in [0, n_samples), the product and the sum each rounded to float32 (the
+ * ADC-to-amps conversion pytesio's reader applies with adctoamp=True; its
+ * coefficients come from the file's detector_config and are passed in here).
+ * A window that does not fit in the stream gives a row of -999999.0 -- "trace
+ * could not be cut", processing_data.py:640-656, 734-736.  The cut windows are
+ * then processed exactly as by ofx_process.  Replaces
+ * H5Reader.read_single_event(trigger_index=, trace_length_samples=,
+ * pretrigger_length_samples=, adctoamp=True) + the truncation of
+ * processing_data.py:640-656, 674-684: only 2 bytes per stream sample cross
+ * PCIe, however many (overlapping) windows are cut from it.
+ */
+int ofx_process_adc(ofx_plan* plan, const int16_t* adc, long long n_stream, int adc_mem,
+                    const long long* trigger_index, long long n_events,
+                    const double* scale, const double* offset,
+                    float* out, int out_mem, void* stream);
+
+/*
  * Device-side synthetic event generator (bench / tests): fills
  * traces[n_traces, n_samples] with  amp_b * roll(template, delay_b) + sigma *
  * white Gaussian noise, counter-based (seed, global trace index) so any shard

@@ -121,6 +121,45 @@ def test_three_template_slots_share_one_pass(engine):
     assert np.allclose(out[:, ow], orc.baseline(x64, 100, 9000), rtol=1e-4, atol=1e-6 * np.abs(x64).max())
 
 
+@pytest.mark.parametrize("n,engine", [(32768, "fused"), (4096, "rocfft")])
+def test_adc_cut_and_convert_front_end(n, engine):
+    """events cut on the GPU from continuous int16 streams
+    (processing_data.py:640-656) equal, bit for bit, the features of the same windows cut
+    and converted on the host; windows that do not fit come back as -999999."""
+    import torch
+    from detprocess_amd import OFPlan
+    pre = n // 2
+    plan, ft, filt, tmpl, psd = _mk(n, engine=engine, max_batch=16)
+    plan.add_search(0, "delay")
+    plan.add_tdwindow(10, n - 10)
+    rng = np.random.default_rng(5)
+    n_stream = 5 * n + 123
+    scale, offset = 2.5e-12, -3.0e-9
+    # a stream with pulses: quantise a synthetic trace train to int16
+    x, _, _ = synth.make_traces(6, tmpl, psd, FS, ft.ampres, seed=8, max_delay=100)
+    train = np.concatenate([x.reshape(-1), np.zeros(n_stream - 6 * n + n)])[:n_stream]
+    adc = np.clip(np.round((train - offset) / scale), -32768, 32767).astype(np.int16)[None, :]
+    trig = np.array([pre, pre + 1, n + pre + 17, 3 * n + 999, pre - 1, n_stream - (n - pre) + 1,
+                     n_stream - (n - pre), 2 * n + pre] + list(rng.integers(pre, n_stream - n, 30)),
+                    dtype=np.int64)
+    out = plan.process_adc(adc, trig, scale, offset)
+    lo = trig - pre
+    ok = (lo >= 0) & (lo + n <= n_stream)
+    assert list(ok[:8]) == [True, True, True, True, False, False, True, True]
+    ev = np.zeros((len(trig), n), dtype=np.float32)
+    for b in np.nonzero(ok)[0]:
+        ev[b] = adc[0, lo[b]:lo[b] + n].astype(np.float32) * np.float32(scale) + np.float32(offset)
+    want = plan.process(ev, valid=ok.astype(np.uint8))
+    assert np.array_equal(out, want)
+    assert np.all(out[~ok] == -999999.0)
+    # device-resident stream gives the same rows
+    out_d = plan.process_adc(torch.as_tensor(adc, device="cuda:0"), trig, scale, offset).cpu().numpy()
+    assert np.array_equal(out_d, out)
+    # and the features are those of the oracle on the converted windows
+    ref = orc.process_events(filt, ev[ok].astype(np.float64), "unconstrained")
+    check_search(out[ok].astype(np.float64), 0, ref, "", ft.ampres, FS, f"adc/{engine}")
+
+
 def test_auto_engine_falls_back_for_wide_lowchi2():
     """lowchi2_fcutoff = 50 kHz covers 1311 bins; the FUSED kernel stashes 512, so an
     AUTO plan runs that call on the general engine (an explicit FUSED plan refuses)."""
