@@ -280,12 +280,42 @@ class FeatureProcessing:
                              f"{len(self._channels)}")
         if self._plans is None or self._compiled_n != shape[2]:
             self._compile(shape[2])
-        result = {}
-        for channel, cp in self._plans.items():
+        def run(cp):
             tr = traces
             if len(self._channels) == 1 and cp.plan.n_channels == 1:
                 tr = traces.reshape(shape[0], shape[2])
-            out = cp.plan.process(tr, valid=valid)
+            return cp.plan.process(tr, valid=valid)
+        return self._collect(run, as_dataframe)
+
+    def process_adc(self, adc, trigger_index, scale, offset, n_samples=None, as_dataframe=True):
+        """Events cut on the GPU out of continuous raw-data streams (SURVEY.md 8f rank 2;
+        processing_data.py:640-656, 674-684).  adc: int16 [C, n_stream] (C =
+        len(available_channels)), NumPy or CUDA tensor; trigger_index: int64 [B];
+        scale / offset: per channel ADC -> amps (pytesio ``adctoamp``); n_samples: trace
+        length (default: the configured ``nb_samples``).  Windows that do not fit in the
+        stream come back as -999999.0."""
+        n = int(n_samples or self._nb_samples or 0)
+        if n <= 0:
+            raise ValueError("ERROR: process_adc needs the trace length (n_samples= or "
+                             "nb_samples in the configuration)")
+        if self._plans is None or self._compiled_n != n:
+            self._compile(n)
+        if adc.shape[0] != len(self._channels):
+            raise ValueError(f"ERROR: adc has {adc.shape[0]} channels, expected "
+                             f"{len(self._channels)}")
+        sc = np.broadcast_to(np.asarray(scale, dtype=np.float64), (len(self._channels),))
+        of = np.broadcast_to(np.asarray(offset, dtype=np.float64), (len(self._channels),))
+
+        def run(cp):
+            if cp.plan.n_channels == 1 and len(self._channels) == 1:
+                return cp.plan.process_adc(adc, trigger_index, sc[:1], of[:1])
+            return cp.plan.process_adc(adc, trigger_index, sc, of)
+        return self._collect(run, as_dataframe)
+
+    def _collect(self, run, as_dataframe):
+        result = {}
+        for channel, cp in self._plans.items():
+            out = run(cp)
             if not isinstance(out, np.ndarray):
                 out = out.cpu().numpy()
             for name, off in cp.columns:

@@ -315,6 +315,43 @@ def test_feature_processing_batch_driver(engine):
 
 
 @pytest.mark.gpu
+def test_feature_processing_from_adc_streams():
+    """The YAML-driven batch driver on events cut from continuous int16 streams equals the
+    same driver on host-cut, host-converted events (4 channels, per-channel conversion)."""
+    from detprocess_amd import FeatureProcessing
+    n, pre = 32768, 16384
+    fd, J = _filter_data(n, pre)
+    tmpl = synth.make_template(n, pre, FS)
+    ampres = 1.0 / np.sqrt(1.0)  # only a scale for the synthetic pulses
+    from oracle import of1x1 as orc
+    filt = orc.OFFilter(tmpl, J, FS, pre)
+    x, _, _ = synth.make_traces(4 * 4, tmpl, J, FS, filt.ampres, seed=77)
+    n_stream = 4 * n
+    scale = np.array([2.0e-12, 2.5e-12, 3.0e-12, 1.5e-12])
+    offset = np.array([-1e-9, 0.0, 2e-9, 5e-10])
+    adc = np.empty((4, n_stream), dtype=np.int16)
+    for c in range(4):
+        train = x[4 * c:4 * c + 4].reshape(-1)
+        adc[c] = np.clip(np.round((train - offset[c]) / scale[c]), -32768, 32767)
+    trig = np.array([pre, n + pre, n + pre + 5000, 3 * n + pre, 3 * n + pre + 1, 100], dtype=np.int64)
+    fp = FeatureProcessing(YAML, fd, CHANS, FS, engine="auto", nb_samples=n,
+                           nb_pretrigger_samples=pre)
+    df = fp.process_adc(adc, trig, scale, offset)
+    lo = trig - pre
+    ok = (lo >= 0) & (lo + n <= n_stream)
+    assert list(ok) == [True, True, True, True, False, False]
+    ev = np.zeros((len(trig), 4, n), dtype=np.float32)
+    for b in np.nonzero(ok)[0]:
+        for c in range(4):
+            ev[b, c] = (adc[c, lo[b]:lo[b] + n].astype(np.float32) * np.float32(scale[c])
+                        + np.float32(offset[c]))
+    df2 = fp.process(ev, valid=ok.astype(np.uint8))
+    assert list(df.columns) == list(df2.columns)
+    assert np.array_equal(df.to_numpy(), df2.to_numpy())
+    assert (df.iloc[4] == -999999.0).all() and (df.iloc[5] == -999999.0).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("engine", ["fused", "rocfft"])
 def test_psd_amp_and_energyabsorbed(engine):
     """psd_amp (algorithms.py:952-1044) and
