@@ -45,6 +45,14 @@ _SYMBOLS = [
     ("ofx_process", C.c_int, [_p, _p, _p, C.c_longlong, C.c_int, _p, C.c_int, _p]),
     ("ofx_process_adc", C.c_int, [_p, _p, C.c_longlong, C.c_int, _p, C.c_longlong, _p, _p, _p,
                                   C.c_int, _p]),
+    ("ofx_trigger_create", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_double, _p, C.c_double,
+                                     C.c_double, C.c_int]),
+    ("ofx_trigger_destroy", C.c_int, [_p]),
+    ("ofx_trigger_update_trace", C.c_int, [_p, _p, C.c_int, C.c_longlong, C.c_int, C.c_double,
+                                           C.c_double, C.c_int, _p]),
+    ("ofx_trigger_get_traces", C.c_int, [_p, _p, _p, C.c_int, _p]),
+    ("ofx_trigger_find", C.c_int, [_p, C.c_double, C.c_longlong, _p, _p, _p, C.c_longlong,
+                                   C.POINTER(C.c_longlong), _p]),
     ("ofx_synth_traces", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                    C.c_ulonglong, _p]),

@@ -1,0 +1,432 @@
+// ofx_trigger.hip -- continuous-data optimal-filter trigger (include/ofx.h, "ofx_trigger"):
+//   update_trace : overlap-save FIR filtering of a long stream with batched rocFFT
+//                  (blocks of P samples advanced by H = P - (N - 1), gathered with the
+//                  int16 / baseline conversion), filtered = conv / vscale,
+//                  delta chi2 = filtered^2 w, edges zeroed   (oftrigger.py:649-679)
+//   find         : threshold, range merging with a static pile-up window, arg-max per range
+//                  (oftrigger.py:976-1019, :29-77) as two device scans + one atomic-max pass
+// All passes are HBM-bound element-wise / scan work around two rocFFT calls.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <rocfft/rocfft.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ofx_common.h"
+
+struct ofx_trigger {
+    int N = 0, pre = 0, device = 0;
+    double fs = 0, vscale = 1, w = 1;
+    int P = 0, H = 0;                     // FFT block length, hop
+    float2* d_hfft = nullptr;             // [P/2+1] FFT of the zero-padded filter / P
+    // per-stream state
+    long long n = 0, nblk = 0;
+    float* d_xpad = nullptr;  size_t xpad_elems = 0;
+    float2* d_spec = nullptr; size_t spec_elems = 0;
+    float* d_yblk = nullptr;  size_t yblk_elems = 0;
+    float* d_filt = nullptr;  float* d_dchi = nullptr; size_t trace_elems = 0;
+    int* d_scan = nullptr;    size_t scan_elems = 0;     // last-above / range-start scans
+    unsigned long long* d_key = nullptr; size_t key_elems = 0;
+    void* d_tmp = nullptr;    size_t tmp_bytes = 0;
+    void* d_stage = nullptr;  size_t stage_bytes = 0;
+    long long* d_count = nullptr;
+    long long* d_oidx = nullptr; float* d_odchi = nullptr; float* d_oamp = nullptr; size_t out_cap = 0;
+    rocfft_plan r2c = nullptr, c2r = nullptr;
+    rocfft_execution_info info = nullptr;
+    void* d_work = nullptr; size_t work_bytes = 0;
+    long long plan_nblk = 0;
+};
+
+namespace {
+
+template <typename T>
+int grow(T** buf, size_t* have, size_t want) {
+    if (*have >= want) return OFX_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    OFX_HIP(hipMalloc(reinterpret_cast<void**>(buf), want * sizeof(T)));
+    *have = want;
+    return OFX_OK;
+}
+
+constexpr int TB = 256;
+
+// block j of the overlap-save scheme, gathered explicitly (rocFFT batches whose input
+// distance is smaller than the transform length came back wrong for every batch but the
+// first): seg[j][i] = x[j H + i - (N-1)] - c0 inside the stream, -c0 outside.  The filter
+// has no DC gain, so removing the constant c0 = x[0] is exact and keeps the fp32 FFT error
+// small for streams riding on a large baseline.
+template <typename T>
+__global__ void k_pad(const T* __restrict__ x, long long n, int front, int P, int H,
+                      long long total, float scale, float offset, float* __restrict__ seg) {
+    const long long idx = (long long)blockIdx.x * TB + threadIdx.x;
+    if (idx >= total) return;
+    const float c0 = (float)x[0] * scale + offset;
+    const long long blk = idx / P;
+    const long long j = blk * H + (idx - blk * P) - front;
+    float v = 0.0f;
+    if (j >= 0 && j < n) v = (float)x[j] * scale + offset;
+    seg[idx] = v - c0;
+}
+
+__global__ void k_mul(float2* __restrict__ spec, const float2* __restrict__ h, int K,
+                      long long total) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= total) return;
+    const float2 a = spec[i], b = h[i % K];
+    spec[i] = make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// 'same' output t corresponds to full-convolution sample nf = t + (N-1)/2, which is sample
+// (N-1) + nf % H of block nf / H.  The constant removed in k_pad does not come back (no DC).
+__global__ void k_dchi2(const float* __restrict__ yblk, long long n, int N, int P, int H,
+                        float inv_vscale, float w, int padding, float* __restrict__ filt,
+                        float* __restrict__ dchi) {
+    const long long t = (long long)blockIdx.x * TB + threadIdx.x;
+    if (t >= n) return;
+    const long long nf = t + (N - 1) / 2;
+    const long long blk = nf / H;
+    const int off = (int)(nf - blk * H) + (N - 1);
+    const float a = yblk[blk * P + off] * inv_vscale;
+    filt[t] = a;
+    float d = a * w * a;
+    if (padding) {
+        // oftrigger.py:676-679: [:N] = 0 and [-(N) + (N+1)%2:] = 0
+        const long long tail = (long long)N - ((N + 1) % 2);
+        if (t < N || t >= n - tail) d = 0.0f;
+    }
+    dchi[t] = d;
+}
+
+__global__ void k_above(const float* __restrict__ dchi, long long n, float thr,
+                        int* __restrict__ last) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    last[i] = (dchi[i] > thr) ? (int)i : -1;
+}
+
+// prev[i] = index of the last above-threshold sample <= i (inclusive max scan of k_above).
+// A range starts at an above-threshold sample whose predecessor is more than `window` away.
+__global__ void k_starts(const float* __restrict__ dchi, const int* __restrict__ prev,
+                         long long n, float thr, long long window, int* __restrict__ start) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    int s = -1;
+    if (dchi[i] > thr) {
+        const int pv = (i > 0) ? prev[i - 1] : -1;
+        if (pv < 0 || (i - pv) > window) s = (int)i;
+    }
+    start[i] = s;
+}
+
+// rstart[i] = start of the range sample i belongs to (inclusive max scan of k_starts).
+// key = (delta chi2 bits, inverted offset): atomicMax keeps the first maximum (np.argmax).
+__global__ void k_best(const float* __restrict__ dchi, const int* __restrict__ rstart,
+                       long long n, float thr, unsigned long long* __restrict__ key) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const float d = dchi[i];
+    if (!(d > thr)) return;
+    const int rs = rstart[i];
+    const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) |
+                                 (unsigned long long)(0xFFFFFFFFu - (unsigned)(i - rs));
+    atomicMax(&key[rs], k);
+}
+
+__global__ void k_emit(const float* __restrict__ dchi, const float* __restrict__ filt,
+                       const int* __restrict__ prev, const unsigned long long* __restrict__ key,
+                       long long n, float thr, long long window, long long cap,
+                       long long* __restrict__ count, long long* __restrict__ oidx,
+                       float* __restrict__ odchi, float* __restrict__ oamp) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    if (!(dchi[i] > thr)) return;
+    const int pv = (i > 0) ? prev[i - 1] : -1;
+    if (!(pv < 0 || (i - pv) > window)) return;            // not a range start
+    const unsigned long long k = key[i];
+    const long long best = i + (long long)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    const long long slot = (long long)atomicAdd(reinterpret_cast<unsigned long long*>(count), 1ull);
+    if (slot < cap) {
+        oidx[slot] = best;
+        odchi[slot] = dchi[best];
+        oamp[slot] = filt[best];
+    }
+}
+
+int blocks_for(long long n) { return (int)((n + TB - 1) / TB); }
+
+int make_plans(ofx_trigger* t, long long nblk, hipStream_t st) {
+    if (t->plan_nblk == nblk && t->r2c) {
+        OFX_FFT(rocfft_execution_info_set_stream(t->info, st));
+        return OFX_OK;
+    }
+    if (t->r2c) rocfft_plan_destroy(t->r2c);
+    if (t->c2r) rocfft_plan_destroy(t->c2r);
+    if (t->info) rocfft_execution_info_destroy(t->info);
+    t->r2c = t->c2r = nullptr;
+    t->info = nullptr;
+    static bool setup_done = false;
+    if (!setup_done) {
+        OFX_FFT(rocfft_setup());
+        setup_done = true;
+    }
+    const size_t len = (size_t)t->P;
+    OFX_FFT(rocfft_plan_create(&t->r2c, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_forward, rocfft_precision_single, 1,
+                               &len, (size_t)nblk, nullptr));
+    OFX_FFT(rocfft_plan_create(&t->c2r, rocfft_placement_notinplace,
+                               rocfft_transform_type_real_inverse, rocfft_precision_single, 1,
+                               &len, (size_t)nblk, nullptr));
+    size_t w1 = 0, w2 = 0;
+    OFX_FFT(rocfft_plan_get_work_buffer_size(t->r2c, &w1));
+    OFX_FFT(rocfft_plan_get_work_buffer_size(t->c2r, &w2));
+    const size_t wb = std::max(w1, w2);
+    if (wb > t->work_bytes) {
+        if (t->d_work) (void)hipFree(t->d_work);
+        t->d_work = nullptr;
+        t->work_bytes = 0;
+        OFX_HIP(hipMalloc(&t->d_work, wb));
+        t->work_bytes = wb;
+    }
+    OFX_FFT(rocfft_execution_info_create(&t->info));
+    if (wb) OFX_FFT(rocfft_execution_info_set_work_buffer(t->info, t->d_work, t->work_bytes));
+    OFX_FFT(rocfft_execution_info_set_stream(t->info, st));
+    t->plan_nblk = nblk;
+    return OFX_OK;
+}
+
+}  // namespace
+
+extern "C" int ofx_trigger_create(ofx_trigger** out, int n_samples, int n_pretrigger, double fs,
+                                  const double* phi_td, double vscale, double w, int device) {
+    if (!out || n_samples < 2 || n_pretrigger < 0 || n_pretrigger >= n_samples || !(fs > 0) ||
+        !phi_td || !(vscale != 0.0) || !(w > 0)) {
+        ofx_set_error("ofx_trigger_create: bad argument");
+        return OFX_ERR_ARG;
+    }
+    OFX_HIP(hipSetDevice(device));
+    ofx_trigger* t = new ofx_trigger();
+    t->N = n_samples;
+    t->pre = n_pretrigger;
+    t->fs = fs;
+    t->vscale = vscale;
+    t->w = w;
+    t->device = device;
+    int P = 1;
+    while (P < 4 * n_samples) P <<= 1;                 // >= 75 % of every block is new output
+    if (P < 4096) P = 4096;
+    t->P = P;
+    t->H = P - (n_samples - 1);
+    // FFT of the zero-padded filter in fp64 on the host (naive O(N P) would be too slow:
+    // use a straightforward radix-2 recursion on the padded array)
+    std::vector<double> re(P, 0.0), im(P, 0.0);
+    for (int i = 0; i < n_samples; ++i) re[i] = phi_td[i];
+    // iterative radix-2 FFT (P is a power of two)
+    for (int i = 1, j = 0; i < P; ++i) {
+        int bit = P >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (int len = 2; len <= P; len <<= 1) {
+        const double ang = -2.0 * M_PI / len;
+        for (int i = 0; i < P; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double wr = std::cos(ang * k), wi = std::sin(ang * k);
+                const double ur = re[i + k], ui = im[i + k];
+                const double vr = re[i + k + len / 2] * wr - im[i + k + len / 2] * wi;
+                const double vi = re[i + k + len / 2] * wi + im[i + k + len / 2] * wr;
+                re[i + k] = ur + vr; im[i + k] = ui + vi;
+                re[i + k + len / 2] = ur - vr; im[i + k + len / 2] = ui - vi;
+            }
+    }
+    const int K = P / 2 + 1;
+    std::vector<float2> h(K);
+    for (int k = 0; k < K; ++k) h[k] = make_float2((float)(re[k] / P), (float)(im[k] / P));
+    if (hipMalloc(&t->d_hfft, sizeof(float2) * K) != hipSuccess ||
+        hipMemcpy(t->d_hfft, h.data(), sizeof(float2) * K, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&t->d_count, sizeof(long long)) != hipSuccess) {
+        ofx_set_error("ofx_trigger_create: device allocation failed");
+        delete t;
+        return OFX_ERR_HIP;
+    }
+    *out = t;
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_destroy(ofx_trigger* t) {
+    if (!t) return OFX_OK;
+    (void)hipSetDevice(t->device);
+    if (t->r2c) rocfft_plan_destroy(t->r2c);
+    if (t->c2r) rocfft_plan_destroy(t->c2r);
+    if (t->info) rocfft_execution_info_destroy(t->info);
+    void* bufs[] = {t->d_hfft, t->d_xpad, t->d_spec, t->d_yblk, t->d_filt, t->d_dchi, t->d_scan,
+                    t->d_key, t->d_tmp, t->d_stage, t->d_count, t->d_oidx, t->d_odchi, t->d_oamp,
+                    t->d_work};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete t;
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_update_trace(ofx_trigger* t, const void* x, int dtype, long long n,
+                                        int mem, double scale, double offset, int padding,
+                                        void* stream) {
+    if (!t || !x || n < 1 || (dtype != 0 && dtype != 1) || n > 2000000000LL) {
+        ofx_set_error("ofx_trigger_update_trace: bad argument");
+        return OFX_ERR_ARG;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int N = t->N, P = t->P, H = t->H, K = P / 2 + 1;
+    const long long nfull_needed = n + (N - 1) / 2;             // full-conv samples used
+    const long long nblk = (nfull_needed + H - 1) / H;
+    const long long total = nblk * P;                            // gathered blocks
+    const size_t esz = dtype == 0 ? 4 : 2;
+    const void* d_x = x;
+    if (mem == OFX_MEM_HOST) {
+        if (t->stage_bytes < (size_t)n * esz) {
+            if (t->d_stage) (void)hipFree(t->d_stage);
+            t->d_stage = nullptr;
+            t->stage_bytes = 0;
+            OFX_HIP(hipMalloc(&t->d_stage, (size_t)n * esz));
+            t->stage_bytes = (size_t)n * esz;
+        }
+        OFX_HIP(hipMemcpyAsync(t->d_stage, x, (size_t)n * esz, hipMemcpyHostToDevice, st));
+        d_x = t->d_stage;
+    }
+    int rc;
+    if ((rc = grow(&t->d_xpad, &t->xpad_elems, (size_t)total))) return rc;
+    if ((rc = grow(&t->d_spec, &t->spec_elems, (size_t)nblk * K))) return rc;
+    if ((rc = grow(&t->d_yblk, &t->yblk_elems, (size_t)nblk * P))) return rc;
+    if (t->trace_elems < (size_t)n) {
+        if (t->d_filt) (void)hipFree(t->d_filt);
+        if (t->d_dchi) (void)hipFree(t->d_dchi);
+        t->d_filt = t->d_dchi = nullptr;
+        t->trace_elems = 0;
+        OFX_HIP(hipMalloc(&t->d_filt, (size_t)n * sizeof(float)));
+        OFX_HIP(hipMalloc(&t->d_dchi, (size_t)n * sizeof(float)));
+        t->trace_elems = (size_t)n;
+    }
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_pad<float>, dim3(blocks_for(total)), dim3(TB), 0, st,
+                           (const float*)d_x, n, N - 1, P, H, total, 1.0f, 0.0f, t->d_xpad);
+    else
+        hipLaunchKernelGGL(k_pad<int16_t>, dim3(blocks_for(total)), dim3(TB), 0, st,
+                           (const int16_t*)d_x, n, N - 1, P, H, total, (float)scale,
+                           (float)offset, t->d_xpad);
+    if ((rc = make_plans(t, nblk, st))) return rc;
+    void* in1[1] = {t->d_xpad};
+    void* out1[1] = {t->d_spec};
+    OFX_FFT(rocfft_execute(t->r2c, in1, out1, t->info));
+    hipLaunchKernelGGL(k_mul, dim3(blocks_for(nblk * K)), dim3(TB), 0, st, t->d_spec, t->d_hfft,
+                       K, nblk * K);
+    void* in2[1] = {t->d_spec};
+    void* out2[1] = {t->d_yblk};
+    OFX_FFT(rocfft_execute(t->c2r, in2, out2, t->info));
+    hipLaunchKernelGGL(k_dchi2, dim3(blocks_for(n)), dim3(TB), 0, st, t->d_yblk, n, N, P, H,
+                       (float)(1.0 / t->vscale), (float)t->w, padding, t->d_filt, t->d_dchi);
+    OFX_HIP(hipGetLastError());
+    t->n = n;
+    t->nblk = nblk;
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_get_traces(ofx_trigger* t, float* filtered, float* dchi, int mem,
+                                      void* stream) {
+    if (!t || t->n == 0) {
+        ofx_set_error("ofx_trigger_get_traces: no trace (call ofx_trigger_update_trace first)");
+        return OFX_ERR_STATE;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    const hipMemcpyKind kind = mem == OFX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (filtered) OFX_HIP(hipMemcpyAsync(filtered, t->d_filt, (size_t)t->n * 4, kind, st));
+    if (dchi) OFX_HIP(hipMemcpyAsync(dchi, t->d_dchi, (size_t)t->n * 4, kind, st));
+    OFX_HIP(hipStreamSynchronize(st));
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_find(ofx_trigger* t, double chi2_threshold, long long window,
+                                long long* index, float* dchi_out, float* amp_out,
+                                long long cap, long long* n_out, void* stream) {
+    if (!t || t->n == 0) {
+        ofx_set_error("ofx_trigger_find: no trace (call ofx_trigger_update_trace first)");
+        return OFX_ERR_STATE;
+    }
+    if (!n_out || cap < 0 || (cap > 0 && (!index || !dchi_out || !amp_out)) || window < 0) {
+        ofx_set_error("ofx_trigger_find: bad argument");
+        return OFX_ERR_ARG;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = t->n;
+    const float thr = (float)chi2_threshold;
+    int rc;
+    if ((rc = grow(&t->d_scan, &t->scan_elems, (size_t)2 * n))) return rc;
+    if ((rc = grow(&t->d_key, &t->key_elems, (size_t)n))) return rc;
+    if (t->out_cap < (size_t)cap) {
+        if (t->d_oidx) (void)hipFree(t->d_oidx);
+        if (t->d_odchi) (void)hipFree(t->d_odchi);
+        if (t->d_oamp) (void)hipFree(t->d_oamp);
+        t->d_oidx = nullptr; t->d_odchi = t->d_oamp = nullptr;
+        t->out_cap = 0;
+        OFX_HIP(hipMalloc(&t->d_oidx, (size_t)cap * sizeof(long long)));
+        OFX_HIP(hipMalloc(&t->d_odchi, (size_t)cap * sizeof(float)));
+        OFX_HIP(hipMalloc(&t->d_oamp, (size_t)cap * sizeof(float)));
+        t->out_cap = (size_t)cap;
+    }
+    int* prev = t->d_scan;
+    int* rstart = t->d_scan + n;
+    size_t need = 0;
+    OFX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, need, prev, prev, hipcub::Max(), (int)n, st));
+    if (need > t->tmp_bytes) {
+        if (t->d_tmp) (void)hipFree(t->d_tmp);
+        t->d_tmp = nullptr;
+        t->tmp_bytes = 0;
+        OFX_HIP(hipMalloc(&t->d_tmp, need));
+        t->tmp_bytes = need;
+    }
+    const int nb = blocks_for(n);
+    hipLaunchKernelGGL(k_above, dim3(nb), dim3(TB), 0, st, t->d_dchi, n, thr, prev);
+    size_t tb = t->tmp_bytes;
+    OFX_HIP(hipcub::DeviceScan::InclusiveScan(t->d_tmp, tb, prev, prev, hipcub::Max(), (int)n, st));
+    hipLaunchKernelGGL(k_starts, dim3(nb), dim3(TB), 0, st, t->d_dchi, prev, n, thr, window, rstart);
+    tb = t->tmp_bytes;
+    OFX_HIP(hipcub::DeviceScan::InclusiveScan(t->d_tmp, tb, rstart, rstart, hipcub::Max(), (int)n, st));
+    OFX_HIP(hipMemsetAsync(t->d_key, 0, (size_t)n * sizeof(unsigned long long), st));
+    OFX_HIP(hipMemsetAsync(t->d_count, 0, sizeof(long long), st));
+    hipLaunchKernelGGL(k_best, dim3(nb), dim3(TB), 0, st, t->d_dchi, rstart, n, thr, t->d_key);
+    hipLaunchKernelGGL(k_emit, dim3(nb), dim3(TB), 0, st, t->d_dchi, t->d_filt, prev, t->d_key, n,
+                       thr, window, cap, t->d_count, t->d_oidx, t->d_odchi, t->d_oamp);
+    OFX_HIP(hipGetLastError());
+    long long cnt = 0;
+    OFX_HIP(hipMemcpyAsync(&cnt, t->d_count, sizeof(long long), hipMemcpyDeviceToHost, st));
+    OFX_HIP(hipStreamSynchronize(st));
+    *n_out = cnt;
+    const long long m = std::min(cnt, cap);
+    if (m > 0) {
+        std::vector<long long> hi(m);
+        std::vector<float> hd(m), ha(m);
+        OFX_HIP(hipMemcpy(hi.data(), t->d_oidx, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost));
+        OFX_HIP(hipMemcpy(hd.data(), t->d_odchi, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        OFX_HIP(hipMemcpy(ha.data(), t->d_oamp, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<long long> order(m);
+        for (long long i = 0; i < m; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](long long a, long long b) { return hi[a] < hi[b]; });
+        for (long long i = 0; i < m; ++i) {
+            index[i] = hi[order[i]];
+            dchi_out[i] = hd[order[i]];
+            amp_out[i] = ha[order[i]];
+        }
+    }
+    if (cnt > cap) {
+        ofx_set_error("ofx_trigger_find: %lld triggers found, capacity %lld", cnt, cap);
+        return OFX_ERR_ARG;
+    }
+    return OFX_OK;
+}

@@ -231,6 +231,54 @@ int ofx_synth_release(void);
 int ofx_plan_kernel_time(ofx_plan* plan, double* avg_ms, long long* n_launches);
 int ofx_plan_enable_timing(ofx_plan* plan, int enable);
 
+/* ------------------------------------------------------------------------
+ * Continuous-data optimal-filter trigger, one channel x one amplitude
+ * (SURVEY.md section 8f rank 3).  Replaces, for that case,
+ * OptimumFilterTrigger.update_trace (detprocess/core/oftrigger.py:588-679) and
+ * the threshold / range-merging / arg-max part of find_triggers_once
+ * (oftrigger.py:884-1035, static pile-up window).
+ * --------------------------------------------------------------------- */
+typedef struct ofx_trigger ofx_trigger;
+
+/*
+ * phi_td: fp64 [n_samples], the time-domain optimal filter ifft(phi).real with
+ * phi[0] = 0 (oftrigger.py:486-489).  vscale: filtered = conv(trace, phi_td) /
+ * vscale (the iweight matrix times the scale of phi); w: the 1x1 weight matrix,
+ * delta_chi2 = filtered^2 * w (oftrigger.py:663-671).
+ */
+int ofx_trigger_create(ofx_trigger** out, int n_samples, int n_pretrigger, double fs,
+                       const double* phi_td, double vscale, double w, int device);
+int ofx_trigger_destroy(ofx_trigger* trig);
+
+/*
+ * update_trace: FIR-filter a continuous stream ('same'-mode linear convolution,
+ * scipy.signal.oaconvolve in the reference; overlap-save with batched rocFFT
+ * here) and form delta chi2; padding != 0 zeroes delta chi2 within n_samples of
+ * both ends exactly as oftrigger.py:674-679.  stream: n values, float32
+ * (dtype 0) or int16 (dtype 1, amps = adc * scale + offset), host or device.
+ * The filtered and delta-chi2 traces stay on the device inside the object;
+ * ofx_trigger_get_traces copies them out (either pointer may be NULL).
+ */
+int ofx_trigger_update_trace(ofx_trigger* trig, const void* stream_data, int dtype,
+                             long long n, int mem, double scale, double offset, int padding,
+                             void* stream);
+int ofx_trigger_get_traces(ofx_trigger* trig, float* filtered, float* delta_chi2, int mem,
+                           void* stream);
+
+/*
+ * find_triggers_once: samples with delta chi2 > chi2_threshold are grouped into
+ * ranges whose consecutive members are at most pileup_window samples apart
+ * (_getchangeslessthanthresh, oftrigger.py:29-77); each range yields its arg-max
+ * (first maximum).  Outputs (HOST arrays of capacity max_triggers, ascending
+ * index): index of the maximum in the stream (WITHOUT the pretrigger shift of
+ * oftrigger.py:1005, which the caller adds), its delta chi2 and its filtered
+ * amplitude.  *n_triggers receives the number found (may exceed max_triggers:
+ * then only the first max_triggers are written and OFX_ERR_ARG is returned).
+ */
+int ofx_trigger_find(ofx_trigger* trig, double chi2_threshold, long long pileup_window,
+                     long long* index, float* delta_chi2, float* amplitude,
+                     long long max_triggers, long long* n_triggers, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

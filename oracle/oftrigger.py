@@ -1,0 +1,113 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement (fp64 NumPy / SciPy) of the continuous-data
+optimal-filter trigger of detprocess, single channel x single amplitude:
+
+    OptimumFilterTrigger.__init__          detprocess/core/oftrigger.py:384-499
+    OptimumFilterTrigger.update_trace      detprocess/core/oftrigger.py:588-679
+    OptimumFilterTrigger.find_triggers_once  :884-1035   (static pile-up window)
+    _getchangeslessthanthresh              :29-77
+    edge exclusion of find_triggers        :851-880
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
+
+PARITY UNPINNED for the part that lives in QETpy (qp.OFBase.phi / weight / iweight, absent
+from /root/reference): restated here as phi_k = conj(S_k) / J_k (S = fft(template), J the
+two-sided PSD, infinite at DC and at ignored peaks), w = norm of oracle/of1x1.py (1 / ampres^2),
+and the product iw x (scale of phi) fixed by the one property the estimator must have: the
+filtered trace of A x template equals A at the pulse, i.e. filtered = conv(trace, phi_td) /
+((1/N) sum_k |S_k|^2 / J_k) = conv / (norm fs).  Everything after the filter -- 'same'-mode
+overlap-add convolution, edge padding, the sigma -> chi2 threshold, range merging, arg-max,
+index shift -- is in the reference tree and is followed line by line.  With phi_td =
+ifft(conj(S)/J) the in-tree arithmetic puts the maximum one sample after onset + pretrigger
+(N even): conv_full peaks at onset + N, 'same' removes (N-1)//2, the shift adds
+pretrigger - N//2; whether QETpy's phi compensates for it cannot be seen from here.
+"""
+import numpy as np
+from scipy import special, stats
+from scipy.signal import oaconvolve
+
+from . import of1x1
+
+
+class OFTrigger:
+    def __init__(self, fs, template, psd, pretrigger_samples, coupling="AC",
+                 ignored_frequency_peaks=None, ignore_harmonics=False):
+        self.fs = float(fs)
+        self.template = np.asarray(template, dtype=np.float64)
+        self.N = self.template.shape[-1]
+        self.pre = int(pretrigger_samples)
+        J = of1x1.effective_psd(np.asarray(psd, dtype=np.float64), self.fs, coupling,
+                                ignored_frequency_peaks, ignore_harmonics)
+        S = np.fft.fft(self.template)
+        with np.errstate(divide="ignore"):
+            phi_fd = np.conj(S) / J
+        phi_fd[~np.isfinite(J)] = 0.0
+        phi_fd[0] = 0.0                                  # oftrigger.py:488 no DC information
+        self.phi_td = np.fft.ifft(phi_fd).real           # oftrigger.py:489
+        self.norm_td = float(np.dot(self.phi_td, self.template))      # oftrigger.py:493 (get_norm)
+        filt = of1x1.OFFilter(self.template, psd, self.fs, self.pre, coupling,
+                              ignored_frequency_peaks, ignore_harmonics)
+        self.w = float(filt.norm)                        # weight matrix (1x1)
+        self.vscale = float(filt.norm) * self.fs         # (1/N) sum |S|^2 / J
+        self.resolution = float(filt.ampres)             # sqrt(diag(iweight)), oftrigger.py:496
+        self.index_shift = self.pre - self.N // 2        # oftrigger.py:455
+        self.filtered = None
+        self.delta_chi2 = None
+
+    def update_trace(self, trace, padding=True):
+        """oftrigger.py:649-679 for n_channels = m_amplitudes = 1."""
+        x = np.asarray(trace, dtype=np.float64).reshape(-1)
+        v = oaconvolve(x, self.phi_td, mode="same")
+        self.filtered = v / self.vscale
+        self.delta_chi2 = self.filtered * self.w * self.filtered
+        if padding:
+            cut = self.N
+            self.delta_chi2[:cut] = 0.0
+            self.delta_chi2[-(cut) + (cut + 1) % 2:] = 0.0
+        return self.filtered, self.delta_chi2
+
+    @staticmethod
+    def chi2_threshold(thresh, m_amplitudes=1):
+        """oftrigger.py:962-975."""
+        if thresh < 25:
+            sf = stats.norm.sf(thresh) * 2
+            return float(special.gammainccinv(m_amplitudes / 2, sf) * 2)
+        return float(thresh) ** 2
+
+    def find_triggers(self, thresh, pileup_window_msec=None, pileup_window_samples=None,
+                      edge_exclusion_msec=None):
+        """find_triggers_once (static window) + the edge exclusion of find_triggers.
+        Returns dict of arrays: trigger_index, trigger_time, trigger_delta_chi2,
+        trigger_amplitude."""
+        window = 0
+        if pileup_window_msec is not None:
+            window = int(pileup_window_msec * self.fs / 1000)
+        elif pileup_window_samples is not None:
+            window = pileup_window_samples
+        thr = self.chi2_threshold(thresh)
+        mask = self.delta_chi2 > thr
+        trig = np.where(mask)[0]
+        idx, dchi, amp = [], [], []
+        if len(trig):
+            # _getchangeslessthanthresh: split where consecutive indices differ by > window
+            cuts = np.where((trig[1:] - trig[:-1]) > window)[0] + 1
+            starts = np.concatenate(([0], cuts))
+            ends = np.concatenate((cuts, [len(trig)]))
+            for s, e in zip(starts, ends):
+                if e > s:
+                    inds = trig[s:e]
+                    i = inds[np.argmax(self.delta_chi2[inds])]
+                    idx.append(i + self.index_shift)
+                    dchi.append(self.delta_chi2[i])
+                    amp.append(self.filtered[i])
+        idx = np.asarray(idx, dtype=np.int64)
+        out = {"trigger_index": idx, "trigger_time": idx / self.fs,
+               "trigger_delta_chi2": np.asarray(dchi, dtype=np.float64),
+               "trigger_amplitude": np.asarray(amp, dtype=np.float64),
+               "chi2_threshold": thr, "pileup_window": window}
+        if edge_exclusion_msec is not None:
+            tmin = edge_exclusion_msec * 1e-3
+            tmax = self.filtered.shape[-1] / self.fs - edge_exclusion_msec * 1e-3
+            keep = (out["trigger_time"] > tmin) & (out["trigger_time"] < tmax)
+            for k in ("trigger_index", "trigger_time", "trigger_delta_chi2", "trigger_amplitude"):
+                out[k] = out[k][keep]
+        return out

@@ -1,0 +1,128 @@
+"""Continuous-data optimal-filter trigger: oracle known-answer tests on
+the CPU, GPU parity against the oracle (detprocess/core/oftrigger.py:588-679, 884-1035)."""
+import numpy as np
+import pytest
+
+from detprocess_amd import synth
+from oracle import oftrigger as ot
+
+FS = 1.25e6
+
+
+def _stream(n_samples, pre, L, seed, n_pulses=12, noise=True):
+    rng = np.random.default_rng(seed)
+    tmpl = synth.make_template(n_samples, pre, FS)
+    psd = synth.make_psd(n_samples, FS)
+    trig = ot.OFTrigger(FS, tmpl, psd, pre)
+    x = np.zeros(L)
+    if noise:
+        # coloured noise consistent with the PSD, generated block-wise and stitched
+        nb = L // n_samples + 2
+        x += synth.coloured_noise(rng, nb, psd, FS).reshape(-1)[:L]
+    onsets = np.sort(rng.integers(2 * n_samples, L - 3 * n_samples, n_pulses))
+    amps = trig.resolution * rng.uniform(8, 80, n_pulses)
+    for p, a in zip(onsets, amps):
+        x[p:p + n_samples] += a * tmpl
+    return tmpl, psd, trig, x, onsets, amps
+
+
+def test_oracle_known_answers():
+    """Noiseless pulses: amplitude exact, index = onset + pretrigger + 1 (see the oracle's
+    header on the one-sample offset of the in-tree arithmetic), pile-up merging by window,
+    edge padding, sigma -> chi2 threshold."""
+    n, pre, L = 4096, 1500, 80000
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    t = ot.OFTrigger(FS, tmpl, psd, pre)
+    x = np.zeros(L)
+    pos = [10000, 30000, 30900, 50000]
+    amps = [1e-7, 2e-7, 0.5e-7, 3e-7]
+    for p, a in zip(pos, amps):
+        x[p:p + n] += a * tmpl
+    filt, dchi = t.update_trace(x)
+    assert np.all(dchi[:n] == 0) and np.all(dchi[-(n) + 1:] == 0)
+    r = t.find_triggers(5.0, pileup_window_samples=2000)
+    assert list(r["trigger_index"]) == [10000 + pre + 1, 30000 + pre + 1, 50000 + pre + 1]
+    assert r["trigger_amplitude"][0] == pytest.approx(1e-7, rel=1e-9)
+    assert r["trigger_amplitude"][2] == pytest.approx(3e-7, rel=1e-9)
+    assert np.allclose(r["trigger_delta_chi2"], r["trigger_amplitude"] ** 2 * t.w)
+    # a window shorter than the gap between the two piled-up excursions separates them
+    r2 = t.find_triggers(5.0, pileup_window_samples=0)
+    assert len(r2["trigger_index"]) >= 4
+    assert ot.OFTrigger.chi2_threshold(5.0) == pytest.approx(25.0, rel=1e-6)
+    assert ot.OFTrigger.chi2_threshold(30.0) == 900.0
+    # edge exclusion keeps triggers strictly inside (oftrigger.py:851-880)
+    r3 = t.find_triggers(5.0, pileup_window_samples=2000, edge_exclusion_msec=10.0)
+    assert list(r3["trigger_index"]) == [30000 + pre + 1, 50000 + pre + 1]
+
+
+def test_oracle_time_domain_equals_frequency_domain_of():
+    """At a pulse the trigger's filtered trace is the of1x1 amplitude at that lag: the FIR
+    filter and the per-event frequency-domain filter are the same estimator."""
+    from oracle import of1x1 as orc
+    n, pre = 4096, 2048
+    tmpl, psd, t, x, onsets, amps = _stream(n, pre, 12 * 4096, seed=3, n_pulses=1, noise=False)
+    filt, _ = t.update_trace(x)
+    p = int(onsets[0])
+    f = orc.OFFilter(tmpl, psd, FS, pre)
+    r = orc.of1x1_nodelay(f, x[p:p + n])
+    assert filt[p + n // 2 + 1] == pytest.approx(r["amp"], rel=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,pre,L", [(4096, 1500, 300000), (32768, 16384, 1500000), (1000, 300, 50001)])
+def test_gpu_trigger_vs_oracle(n, pre, L):
+    import torch
+    from detprocess_amd import OptimumFilterTrigger
+    tmpl, psd, t, x, onsets, amps = _stream(n, pre, L, seed=11)
+    x32 = x.astype(np.float32)
+    filt, dchi = t.update_trace(x32.astype(np.float64))
+    g = OptimumFilterTrigger("chanA", FS, tmpl, psd, pre)
+    assert g.get_resolution()[0] == pytest.approx(t.resolution, rel=1e-12)
+    assert g.get_norm() == pytest.approx(t.norm_td, rel=1e-9)
+    g.update_trace(x32)
+    gf = g.get_filtered_trace()[0].astype(np.float64)
+    gd = g.get_filtered_delta_chi2().astype(np.float64)
+    scale = np.max(np.abs(filt))
+    assert np.max(np.abs(gf - filt)) <= 2e-5 * scale
+    assert np.all(gd[:n] == 0) and np.all(gd[L - n + 1:] == 0)
+    assert np.max(np.abs(gd - dchi)) <= 4e-5 * np.max(dchi)
+    for window in (0, 200, 2 * n):
+        ref = t.find_triggers(5.0, pileup_window_samples=window)
+        g.find_triggers(5.0, pileup_window_samples=window)
+        td = g.get_trigger_data()["chanA"]
+        thr = ref["chi2_threshold"]
+        assert g.get_chi2_threshold() == pytest.approx(thr, rel=1e-12)
+        # triggers clear of the threshold must agree exactly; samples within fp32 rounding
+        # of the threshold may fall on either side
+        margin = 1e-3 * thr + 4e-5 * np.max(dchi)
+        ri = {int(i): (d, a) for i, d, a in zip(ref["trigger_index"], ref["trigger_delta_chi2"],
+                                                 ref["trigger_amplitude"])}
+        gi = {int(i): (d, a) for i, d, a in zip(td["trigger_index"], td["trigger_delta_chi2"],
+                                                 td["trigger_amplitude"])}
+        clear_ref = {i for i, (d, a) in ri.items() if d > thr + margin}
+        clear_gpu = {i for i, (d, a) in gi.items() if d > thr + margin}
+        if window >= 200:
+            assert clear_ref <= set(gi) and clear_gpu <= set(ri), (window, clear_ref ^ clear_gpu)
+        common = set(ri) & set(gi)
+        assert len(common) >= 0.9 * max(len(ri), 1)
+        for i in common:
+            assert gi[i][1] == pytest.approx(ri[i][1], rel=2e-5, abs=2e-5 * scale)
+            assert gi[i][0] == pytest.approx(ri[i][0], rel=1e-4, abs=margin)
+        assert td["trigger_index_chanA"] == td["trigger_index"]
+        assert td["trigger_type"] == [4] * len(td["trigger_index"])
+    # every injected pulse is found one sample after onset + pretrigger (static 2N window)
+    found = np.array(td["trigger_index"])
+    for p, a in zip(onsets, amps):
+        near = found[np.abs(found - (p + pre + 1)) <= 3]
+        isolated = np.min(np.abs(onsets[onsets != p] - p)) > 3 * n if len(onsets) > 1 else True
+        if isolated:
+            assert len(near) == 1
+    # device-resident input and int16 input give the same filtered trace
+    g.update_trace(torch.as_tensor(x32, device="cuda:0"))
+    assert np.array_equal(g.get_filtered_trace()[0], gf.astype(np.float32))
+    sc = float(np.max(np.abs(x32))) / 30000.0
+    adc = np.round(x32 / sc).astype(np.int16)
+    g.update_trace(adc, adc_scale=sc)
+    t.update_trace(adc.astype(np.float64) * np.float32(sc))
+    assert np.max(np.abs(g.get_filtered_trace()[0] - t.filtered)) <= 2e-5 * scale
