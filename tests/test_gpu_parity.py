@@ -79,6 +79,36 @@ def test_interpolate_vs_oracle(n, engine):
 
 
 @pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("pre", [7, 1000, 20001, 32760])
+def test_pretrigger_away_from_the_middle(engine, pre):
+    """Rolled-index arithmetic (index = lag + pretrigger mod N) with the template onset
+    anywhere in the trace, including a few samples from either end."""
+    n = 32768
+    plan, ft, filt, tmpl, psd = _mk(n, pre=pre, engine=engine)
+    s0 = plan.add_search(0, "nodelay")
+    s1 = plan.add_search(0, "delay")
+    lo, hi = max(0, pre - 200), min(n, pre + 300)
+    s2 = plan.add_search(0, "delay", lo, hi, interpolate=True)
+    s3 = plan.add_search(0, "delay", lo, hi, outside=True)
+    x, _, _ = synth.make_traces(13, tmpl, psd, FS, ft.ampres, seed=pre, max_delay=150)
+    x32 = x.astype(np.float32)
+    x64 = x32.astype(np.float64)
+    out = _run(plan, x32)
+    check_search(out, plan.search_offset(0, s0), orc.process_events(filt, x64, "nodelay"), "",
+                 ft.ampres, FS, f"pre{pre}/nodelay")
+    check_search(out, plan.search_offset(0, s1), orc.process_events(filt, x64, "unconstrained"), "",
+                 ft.ampres, FS, f"pre{pre}/delay")
+    check_search(out, plan.search_offset(0, s2),
+                 orc.process_events(filt, x64, "constrained", interpolate=True,
+                                    window_min_index=lo, window_max_index=hi), "",
+                 ft.ampres, FS, f"pre{pre}/window", interpolated=True)
+    check_search(out, plan.search_offset(0, s3),
+                 orc.process_events(filt, x64, "constrained", window_min_index=lo,
+                                    window_max_index=hi, lgc_outside_window=True), "",
+                 ft.ampres, FS, f"pre{pre}/outside")
+
+
+@pytest.mark.parametrize("engine", ["fused", "rocfft"])
 def test_three_template_slots_share_one_pass(engine):
     """BASELINE configs[3] shape: three template tags (pulse / glitch / muon) on one plan.
     The FUSED engine runs them in one launch on the shared forward transform; every slot
