@@ -122,6 +122,8 @@ struct ofx_plan {
     float2* d_filt = nullptr;            // [max_batch, K]
     float* d_amp = nullptr;              // [max_batch, N]
     float* d_chi0 = nullptr;             // [max_batch]
+    float2* d_vlow = nullptr;            // [max_batch, vlow_cap] low bins of V (lowchi2, psd_amp)
+    int vlow_cap = 0;
     // staging for host buffers
     float* d_stage_in = nullptr;
     size_t stage_in_floats = 0;

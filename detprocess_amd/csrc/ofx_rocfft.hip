@@ -1,9 +1,16 @@
 // ofx_rocfft.hip -- ROCFFT engine: the unfused pipeline named by north_star
-//   [prep/time-domain kernel] -> rocFFT R2C -> filter-apply + chi2_0 kernel
-//   -> rocFFT C2R -> arg-max / chi2 / lowchi2 kernel.
+//   [prep/time-domain kernel] -> rocFFT forward -> filter-apply + chi2_0 kernel
+//   -> rocFFT inverse -> arg-max / chi2 / lowchi2 kernel.
+// The real trace of N samples is transformed as M = N/2 packed complex points
+// (z[m] = x[2m] + i x[2m+1]) with rocFFT's complex plans, and ONE kernel (k_mid) does the
+// real-FFT unpack, the filter multiply, chi2_0 and the re-pack for the inverse: rocFFT's own
+// real-transform plans spend two extra full passes over the data (r2c post-, c2r
+// pre-processing kernels) on exactly that algebra.
 // Handles any even trace length; the FUSED engine (ofx_fused.hip) replaces it
 // for the power-of-two lengths it supports.  Also the on-device cross-check of
 // the fused kernel in the GPU tests.
+#include <algorithm>
+
 #include "ofx_common.h"
 #include "ofx_device.h"
 
@@ -70,8 +77,8 @@ __global__ __launch_bounds__(RB) void k_prep(OfxPlanDev pd, const float* __restr
 // psd_amp bands: mean over bins [k_lo, k_hi) of sqrt(w_k |V_k|^2 / (N fs))
 // (algorithms.py:1013-1038).  One block per trace.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RB) void k_bands(OfxPlanDev pd, const float2* __restrict__ spec,
-                                              const uint8_t* __restrict__ valid,
+__global__ __launch_bounds__(RB) void k_bands(OfxPlanDev pd, const float2* __restrict__ vlow,
+                                              int cap, const uint8_t* __restrict__ valid,
                                               float* __restrict__ out) {
     __shared__ float scratch[RB / OFX_WAVE];
     const size_t b = blockIdx.x;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(RB) void k_bands(OfxPlanDev pd, const float2* __res
         for (int i = threadIdx.x; i < pd.n_bands; i += RB) row[pd.band[i].out_off] = OFX_SENTINEL;
         return;
     }
-    const float2* V = spec + b * pd.K;
+    const float2* V = vlow + b * cap;
     const float c = 1.0f / ((float)pd.N * pd.fs);
     for (int i = 0; i < pd.n_bands; ++i) {
         const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
@@ -96,26 +103,67 @@ __global__ __launch_bounds__(RB) void k_bands(OfxPlanDev pd, const float2* __res
 }
 
 // ---------------------------------------------------------------------------
-// filter apply: Y_k = wf_k V_k ; chi2_0 = sum_k w_k g_k |V_k|^2.  One block per
-// trace (OFBase.calc_signal_filt + chi2_0 -- processing_data.py:771).
+// middle step on the packed spectrum Z = FFT_M(z), M = N/2 (OFBase.calc_signal_filt +
+// chi2_0 -- processing_data.py:771).  For the pair (k, p = M - k):
+//   u = Z_k + conj(Z_p), w = Z_k - conj(Z_p), s = i t_k w, t_k = exp(-2 pi i k / N)
+//   V_k = (u - s)/2, conj(V_p) = (u + s)/2             spectrum of the real trace
+//   chi2_0 += w_k g_k |V_k|^2 + w_p g_p |V_p|^2
+//   Y = wf V;  Ye = Y_k + conj(Y_p), Yo = (Y_k - conj(Y_p)) conj(t_k)
+//   Z'_k = Ye + i Yo,  Z'_p = conj(Ye - i Yo)          inverse FFT_M gives A(2m) + i A(2m+1)
+// k = 0 pairs DC with Nyquist; k = M/2 (M even) pairs with itself.  V_k for k < cap is
+// kept for the low-frequency chi2 and the psd_amp bands.  One block per trace.
+// wf == nullptr: spectrum extraction only (bands without a filter slot).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(RB) void k_filter(int K, int N, const float2* __restrict__ wf,
-                                               const float* __restrict__ g,
-                                               const float2* __restrict__ spec,
-                                               float2* __restrict__ filt,
-                                               float* __restrict__ chi0) {
+__global__ __launch_bounds__(RB) void k_mid(int M, int N, const float2* __restrict__ wf,
+                                            const float* __restrict__ g,
+                                            const float2* __restrict__ zspec,
+                                            float2* __restrict__ zfilt, float* __restrict__ chi0,
+                                            float2* __restrict__ vlow, int cap) {
     __shared__ float scratch[RB / OFX_WAVE];
     const size_t b = blockIdx.x;
-    const float2* V = spec + b * K;
-    float2* Y = filt + b * K;
+    const float2* Z = zspec + b * M;
+    float2* Zo = zfilt ? zfilt + b * M : nullptr;
+    float2* VL = vlow ? vlow + b * cap : nullptr;
     float acc = 0.0f;
-    for (int k = threadIdx.x; k < K; k += RB) {
-        const float2 v = V[k];
-        const float2 w = wf[k];
-        Y[k] = make_float2(w.x * v.x - w.y * v.y, w.x * v.y + w.y * v.x);
-        const float wt = (k == 0 || 2 * k == N) ? 1.0f : 2.0f;
-        acc = fmaf(wt * g[k], v.x * v.x + v.y * v.y, acc);
+    for (int k = threadIdx.x; k <= M / 2; k += RB) {
+        const int p = (k == 0) ? 0 : M - k;
+        const float2 zk = Z[k], zp = Z[p];
+        float2 vk, vpc;                                  // V_k, conj(V_p)
+        float sn, cs;
+        sincospif(-2.0f * (float)k / (float)N, &sn, &cs);          // t_k
+        if (k == 0) {
+            vk = make_float2(zk.x + zk.y, 0.0f);                    // V_0   (DC)
+            vpc = make_float2(zk.x - zk.y, 0.0f);                   // V_M   (Nyquist)
+        } else {
+            const float2 u = make_float2(zk.x + zp.x, zk.y - zp.y);
+            const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
+            // s = i t w
+            const float2 sv = make_float2(-(cs * w.y + sn * w.x), cs * w.x - sn * w.y);
+            vk = make_float2(0.5f * (u.x - sv.x), 0.5f * (u.y - sv.y));
+            vpc = make_float2(0.5f * (u.x + sv.x), 0.5f * (u.y + sv.y));
+        }
+        const int kp = (k == 0) ? M : p;                 // one-sided bin of the partner
+        if (VL) {
+            if (k < cap) VL[k] = vk;
+            if (kp < cap && kp != k) VL[kp] = make_float2(vpc.x, -vpc.y);
+        }
+        if (!wf) continue;
+        const float wk = (k == 0) ? 1.0f : 2.0f;
+        const float wp = (kp == M) ? 1.0f : 2.0f;
+        acc = fmaf(wk * g[k], vk.x * vk.x + vk.y * vk.y, acc);
+        if (kp != k) acc = fmaf(wp * g[kp], vpc.x * vpc.x + vpc.y * vpc.y, acc);
+        // Y_k = wf_k V_k ; conj(Y_p) = conj(wf_p) conj(V_p)
+        const float2 a = wf[k], c = wf[kp];
+        const float2 yk = make_float2(a.x * vk.x - a.y * vk.y, a.x * vk.y + a.y * vk.x);
+        const float2 ypc = make_float2(c.x * vpc.x + c.y * vpc.y, c.x * vpc.y - c.y * vpc.x);
+        const float2 ye = make_float2(yk.x + ypc.x, yk.y + ypc.y);
+        const float2 d = make_float2(yk.x - ypc.x, yk.y - ypc.y);
+        // Yo = d conj(t)
+        const float2 yo = make_float2(d.x * cs + d.y * sn, d.y * cs - d.x * sn);
+        Zo[k] = make_float2(ye.x - yo.y, ye.y + yo.x);                  // Ye + i Yo
+        if (p != k) Zo[p] = make_float2(ye.x + yo.y, -(ye.y - yo.x));   // conj(Ye - i Yo)
     }
+    if (!wf) return;
     acc = ofx_block_sum(acc, scratch);
     if (threadIdx.x == 0) chi0[b] = acc;
 }
@@ -127,7 +175,7 @@ __global__ __launch_bounds__(RB) void k_filter(int K, int N, const float2* __res
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(RB) void k_search(OfxPlanDev pd, OfxSlotDev sd,
                                                const float* __restrict__ amps,
-                                               const float2* __restrict__ spec,
+                                               const float2* __restrict__ vlow, int cap,
                                                const float* __restrict__ chi0v,
                                                const uint8_t* __restrict__ valid,
                                                float* __restrict__ out) {
@@ -143,17 +191,25 @@ __global__ __launch_bounds__(RB) void k_search(OfxPlanDev pd, OfxSlotDev sd,
     }
     const int N = pd.N, pre = pd.pre;
     const float* a = amps + b * N;
-    const float2* V = spec + b * pd.K;
+    const float2* V = vlow + b * cap;
     const float chi0 = chi0v[b];
 
     for (int q = 0; q < sd.n_search; ++q) {
         const OfxSearchDev sq = sd.search[q];
+        // a thread visits its rolled bins in increasing order, so "larger A^2, ties to the
+        // smaller index" is a strict greater-than; the amplitude is fetched once at the end
         OfxCand best = ofx_cand_none();
         auto scan = [&](int i0, int i1) {
+#pragma unroll 4
             for (int i = i0 + threadIdx.x; i < i1; i += RB) {
                 int n = i - pre;
                 if (n < 0) n += N;
-                ofx_cand_take(best, a[n], i);
+                const float v = a[n];
+                const float key = v * v;
+                if (key > best.key) {
+                    best.key = key;
+                    best.idx = i;
+                }
             }
         };
         if (sq.outside) {
@@ -161,6 +217,11 @@ __global__ __launch_bounds__(RB) void k_search(OfxPlanDev pd, OfxSlotDev sd,
             scan(sq.hi, N);
         } else {
             scan(sq.lo, sq.hi);
+        }
+        if (best.idx != 0x7fffffff) {
+            int n = best.idx - pre;
+            if (n < 0) n += N;
+            best.amp = a[n];
         }
         best = ofx_cand_block_reduce(best, cscratch);
         const int d = best.idx - pre;
@@ -196,12 +257,12 @@ static int get_fft(ofx_plan* p, int batch, hipStream_t st, OfxFftPlans** out) {
             setup_done = true;
         }
         OfxFftPlans f;
-        size_t len = (size_t)p->N;
+        size_t len = (size_t)p->N / 2;           // packed complex points
         OFX_FFT(rocfft_plan_create(&f.r2c, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_forward,
+                                   rocfft_transform_type_complex_forward,
                                    rocfft_precision_single, 1, &len, (size_t)batch, nullptr));
         OFX_FFT(rocfft_plan_create(&f.c2r, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_inverse,
+                                   rocfft_transform_type_complex_inverse,
                                    rocfft_precision_single, 1, &len, (size_t)batch, nullptr));
         size_t w1 = 0, w2 = 0;
         OFX_FFT(rocfft_plan_get_work_buffer_size(f.r2c, &w1));
@@ -240,6 +301,9 @@ int ofx_rocfft_release(ofx_plan* p) {
     p->d_trace = nullptr;
     p->d_spec = p->d_filt = nullptr;
     p->d_amp = p->d_chi0 = nullptr;
+    if (p->d_vlow) (void)hipFree(p->d_vlow);
+    p->d_vlow = nullptr;
+    p->vlow_cap = 0;
     return OFX_OK;
 }
 
@@ -258,6 +322,21 @@ int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_vali
         OFX_HIP(hipMalloc(&p->d_amp, sizeof(float) * (size_t)MB * N));
         OFX_HIP(hipMalloc(&p->d_chi0, sizeof(float) * (size_t)MB));
     }
+    // low bins of the trace spectrum kept for lowchi2 / psd_amp
+    int cap = 1;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s)
+        if (p->slot[s].set)
+            for (const OfxSearchDev& q : p->slot[s].searches) cap = std::max(cap, q.nlow);
+    for (const auto& bd : p->bands) cap = std::max(cap, bd.k_hi);
+    if (cap > K) cap = K;
+    if (any_slot && p->vlow_cap < cap) {
+        if (p->d_vlow) (void)hipFree(p->d_vlow);
+        p->d_vlow = nullptr;
+        p->vlow_cap = 0;
+        OFX_HIP(hipMalloc(&p->d_vlow, sizeof(float2) * (size_t)MB * cap));
+        p->vlow_cap = cap;
+    }
+    cap = p->vlow_cap > 0 ? p->vlow_cap : cap;
     if (need_combine && any_slot && !p->d_trace)
         OFX_HIP(hipMalloc(&p->d_trace, sizeof(float) * (size_t)MB * N));
 
@@ -285,19 +364,30 @@ int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_vali
         rc = ofx_time_begin(p, st, &tix);
         if (rc) return rc;
         OFX_FFT(rocfft_execute(f->r2c, in1, out1, f->info_r2c));
-        if (!p->bands.empty())
-            hipLaunchKernelGGL(k_bands, dim3(nb), dim3(RB), 0, st, pd, p->d_spec, vld, out);
+        bool bands_done = p->bands.empty();
+        bool any_search = false;
         for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
             if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
+            any_search = true;
             OfxSlotDev sd;
             ofx_fill_slot_dev(p, s, &sd);
-            hipLaunchKernelGGL(k_filter, dim3(nb), dim3(RB), 0, st, K, N, sd.wf, sd.g,
-                               p->d_spec, p->d_filt, p->d_chi0);
+            hipLaunchKernelGGL(k_mid, dim3(nb), dim3(RB), 0, st, N / 2, N, sd.wf, sd.g, p->d_spec,
+                               p->d_filt, p->d_chi0, p->d_vlow, cap);
+            if (!bands_done) {
+                hipLaunchKernelGGL(k_bands, dim3(nb), dim3(RB), 0, st, pd, p->d_vlow, cap, vld, out);
+                bands_done = true;
+            }
             void* in2[1] = {(void*)p->d_filt};
             void* out2[1] = {(void*)p->d_amp};
             OFX_FFT(rocfft_execute(f->c2r, in2, out2, f->info_c2r));
             hipLaunchKernelGGL(k_search, dim3(nb), dim3(RB), 0, st, pd, sd, p->d_amp,
-                               p->d_spec, p->d_chi0, vld, out);
+                               p->d_vlow, cap, p->d_chi0, vld, out);
+        }
+        if (!any_search && !bands_done) {        // psd_amp without a filter slot
+            hipLaunchKernelGGL(k_mid, dim3(nb), dim3(RB), 0, st, N / 2, N,
+                               (const float2*)nullptr, (const float*)nullptr, p->d_spec,
+                               (float2*)nullptr, (float*)nullptr, p->d_vlow, cap);
+            hipLaunchKernelGGL(k_bands, dim3(nb), dim3(RB), 0, st, pd, p->d_vlow, cap, vld, out);
         }
         rc = ofx_time_end(p, st, tix);
         if (rc) return rc;
