@@ -41,14 +41,17 @@ class _ChannelPlan:
         self.plan = None
         self.columns = []       # (column name, row offset)
         self.energy = []        # (column name, base window off, window off, n, vb, i0, rl)
+        self.external = []      # (algorithm, base, kwargs, yaml params, needs OFBase)
 
 
 class FeatureProcessing:
     def __init__(self, config, filter_data, available_channels, sample_rate,
                  nb_samples=None, nb_pretrigger_samples=None, device=0, engine="auto",
-                 max_batch=8192, window_policy="qetpy"):
+                 max_batch=8192, window_policy="qetpy", external_file=None):
         """config: YamlConfig, YAML path / text, or dict.  available_channels: the
-        channel names of axis 1 of the event array, in order."""
+        channel names of axis 1 of the event array, in order.  external_file: a Python
+        file exposing ``class FeatureExtractors`` with user algorithms
+        (features.py:248-263, 1002-1029)."""
         if isinstance(available_channels, str):
             available_channels = [available_channels]
         self._channels = list(available_channels)
@@ -64,6 +67,31 @@ class FeatureProcessing:
         self._nb_samples = nb_samples
         self._nb_pretrigger = nb_pretrigger_samples
         self._plans = None
+        self._ext = None
+        self._ext_names = []
+        if external_file is not None:
+            self._ext, self._ext_names = self._load_external_extractors(external_file)
+
+    @staticmethod
+    def _load_external_extractors(external_file):
+        """features.py:1002-1029 (load) and 1105-1131 (duplicates of built-ins rejected)."""
+        import importlib.util
+        from .algorithms import FeatureExtractors
+        spec = importlib.util.spec_from_file_location("detprocess_amd._external", external_file)
+        module = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(module)
+        fe_ext = module.FeatureExtractors
+        internal = [a for a in dir(FeatureExtractors) if a[0] != "_"]
+        names = []
+        for attribute in dir(fe_ext):
+            if attribute[0] == "_":
+                continue
+            if attribute in internal:
+                raise ValueError("External algorithm " + attribute
+                                 + " is a duplicate from internal feature extractor!"
+                                 + " This is nto allowed. You need to change name...")
+            names.append(attribute)
+        return fe_ext, names
 
     # ----------------------------------------------------------------- compile
     def _compile(self, n_samples):
@@ -143,13 +171,24 @@ class FeatureProcessing:
                     if not params.get("f_lims"):
                         raise ValueError('ERROR: "f_lims" required for algorithm psd_amps')
                     pending.append(("band", algorithm, base, None, params, wmin, wmax, npre))
+                elif base in self._ext_names:
+                    # user algorithm (features.py:749-752): same injected kwargs as built-ins
+                    kw = dict(kwargs)
+                    kw["window_min_index"], kw["window_max_index"] = wmin, wmax
+                    kw["feature_base_name"] = algorithm
+                    cp.external.append((algorithm, base, kw, params,
+                                        any(p in base for p in OF_BASE_PREFIXES)))
                 elif any(p in base for p in OF_BASE_PREFIXES):
                     raise NotImplementedError(
                         f'algorithm "{base}" is outside the of1x1 hot path of this engine')
                 else:
                     raise ValueError(f'ERROR: Cannot find algorithm "{base}" anywhere. '
                                      f"Check feature extractor exists!")
+            cp.channel, cp.feature_channel = channel, feature_channel
+            cp.chan_index, cp.chan_weight, cp.chan_names = idx, w, names
             if not pending:
+                if cp.external:
+                    plans[channel] = cp
                 continue
             # psd_amp bands ride on a filter slot in the FUSED engine (and only the
             # lowest bins); otherwise the general ROCFFT engine carries them
@@ -285,7 +324,7 @@ class FeatureProcessing:
             if len(self._channels) == 1 and cp.plan.n_channels == 1:
                 tr = traces.reshape(shape[0], shape[2])
             return cp.plan.process(tr, valid=valid)
-        return self._collect(run, as_dataframe)
+        return self._collect(run, as_dataframe, traces=traces, valid=valid)
 
     def process_adc(self, adc, trigger_index, scale, offset, n_samples=None, as_dataframe=True):
         """Events cut on the GPU out of continuous raw-data streams (SURVEY.md 8f rank 2;
@@ -312,9 +351,62 @@ class FeatureProcessing:
             return cp.plan.process_adc(adc, trigger_index, sc, of)
         return self._collect(run, as_dataframe)
 
-    def _collect(self, run, as_dataframe):
+    def _run_external(self, cp, traces, valid, result):
+        """User algorithms of an ``external_file`` (features.py:749-752, 826-839).  Trace
+        algorithms are called once per event with the float64 channel trace, as the
+        reference does; algorithms whose base name asks for an OF base
+        (processing_data.py:93-97) get a ``detprocess_amd.OFBase`` holding the whole batch."""
+        if traces is None:
+            raise NotImplementedError("external extractors need the float events "
+                                      "(FeatureProcessing.process)")
+        tr = traces.cpu().numpy() if not isinstance(traces, np.ndarray) else traces
+        B = tr.shape[0]
+        comb = np.zeros((B, tr.shape[2]), dtype=np.float64)
+        for j, wj in zip(cp.chan_index, cp.chan_weight):
+            comb += float(wj) * tr[:, j, :].astype(np.float64)
+        ok = np.ones(B, dtype=bool) if valid is None else np.asarray(valid).astype(bool)
+        for algorithm, base, kw, params, needs_of in cp.external:
+            extractor = getattr(self._ext, base)
+            if needs_of:
+                from .ofbase import OFBase
+                fchan = (cp.channel if cp.channel in self._filter_data._filter_data
+                         else cp.chan_names[0])
+                ob = OFBase(self._fs, device=self._device, engine=self._engine)
+                csd, _, _ = self._filter_data.get_csd(fchan, tag=params.get("csd_tag", "default"),
+                                                      fold=False, return_metadata=True)
+                ob.set_csd(cp.channel, csd, coupling=params.get("coupling", "AC"),
+                           ignored_frequency_peaks=params.get("ignored_frequency_peaks"),
+                           ignore_harmonics=bool(params.get("ignore_harmonics", False)))
+                if "template_tag" in params:
+                    template, _, _ = self._filter_data.get_template(
+                        fchan, tag=params["template_tag"], return_metadata=True)
+                    ob.add_template(cp.channel, template, template_tag=params["template_tag"],
+                                    pretrigger_samples=kw["nb_pretrigger_samples"])
+                    ob.calc_phi(cp.channel, params["template_tag"])
+                ob.update_signal(cp.channel, comb.astype(np.float32), calc_fft=True)
+                feats = extractor(cp.channel, ob, **kw)
+                for name, val in feats.items():
+                    arr = np.broadcast_to(np.asarray(val, dtype=np.float64), (B,)).copy()
+                    arr[~ok] = -999999.0
+                    result[f"{name}_{cp.feature_channel}"] = arr
+                continue
+            cols = {}
+            for b in range(B):
+                if not ok[b]:
+                    continue
+                feats = extractor(comb[b], **kw)
+                for name, val in feats.items():
+                    cols.setdefault(name, np.full(B, -999999.0))[b] = val
+            for name, arr in cols.items():
+                result[f"{name}_{cp.feature_channel}"] = arr
+
+    def _collect(self, run, as_dataframe, traces=None, valid=None):
         result = {}
         for channel, cp in self._plans.items():
+            if cp.external:
+                self._run_external(cp, traces, valid, result)
+            if cp.plan is None:
+                continue
             out = run(cp)
             if not isinstance(out, np.ndarray):
                 out = out.cpu().numpy()

@@ -314,6 +314,76 @@ def test_feature_processing_batch_driver(engine):
                        rtol=1e-4, atol=1e-6 * np.abs(xs).max() * n / FS)
 
 
+EXT_FILE = '''
+import numpy as np
+import detprocess_amd as da
+
+
+class FeatureExtractors:
+    @staticmethod
+    def minmax(trace, window_min_index=None, window_max_index=None, feature_base_name="minmax",
+               **kwargs):
+        if window_min_index is None:
+            window_min_index = 0
+        if window_max_index is None:
+            window_max_index = trace.shape[-1] - 1
+        w = trace[window_min_index:window_max_index]
+        return {feature_base_name: np.amax(w) - np.amin(w)}
+
+    @staticmethod
+    def of1x1_twice(channel, of_base, template_tag="default", feature_base_name="of1x1_twice",
+                    **kwargs):
+        r = da.FeatureExtractors.of1x1_unconstrained(channel, of_base, template_tag=template_tag,
+                                                     feature_base_name="tmp")
+        return {"amp2_" + feature_base_name: 2.0 * np.asarray(r["amp_tmp"])}
+'''
+
+
+@pytest.mark.gpu
+def test_external_extractor_file(tmp_path):
+    """Plugin mechanism (features.py:248-263, 1002-1029, 1105-1131): user algorithms from
+    an external file, trace-based and OF-based, with the injected kwargs and column naming
+    of the reference; duplicates of built-ins are rejected."""
+    from detprocess_amd import FeatureProcessing
+    from oracle import of1x1 as orc
+    n, pre, B = 32768, 16384, 5
+    fd, J = _filter_data(n, pre)
+    tmpl = synth.make_template(n, pre, FS)
+    filt = orc.OFFilter(tmpl, J, FS, pre)
+    ev, _, _ = synth.make_traces(B * 4, tmpl, J, FS, filt.ampres, seed=12)
+    ev = ev.reshape(B, 4, n).astype(np.float32)
+    ext = tmp_path / "features_user.py"
+    ext.write_text(EXT_FILE)
+    yaml_text = YAML.replace("    energyabsorbed:\n        run: False\n        i0: 88e-9\n",
+                             "    minmax:\n        run: True\n        window_min_from_trig_usec: -500\n"
+                             "        window_max_from_trig_usec: 500\n"
+                             "    mm_all:\n        run: True\n        base_algorithm: minmax\n"
+                             "    of1x1_twice:\n        run: True\n        template_tag: default\n")
+    assert "minmax" in yaml_text
+    fp = FeatureProcessing(yaml_text, fd, CHANS, FS, external_file=str(ext))
+    valid = np.array([1, 1, 0, 1, 1], dtype=np.uint8)
+    df = fp.process(ev, valid=valid)
+    ok = valid.astype(bool)
+    x = ev[:, 0, :].astype(np.float64)
+    lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_trig_usec=-500,
+                                    window_max_from_trig_usec=500)
+    want = np.array([x[b, lo:hi].max() - x[b, lo:hi].min() for b in range(B)])
+    assert np.allclose(df["minmax_Melange1pc1ch"][ok], want[ok], rtol=1e-12)
+    want_all = np.array([x[b, 0:n - 1].max() - x[b, 0:n - 1].min() for b in range(B)])
+    assert np.allclose(df["mm_all_Melange1pc1ch"][ok], want_all[ok], rtol=1e-12)
+    assert df["minmax_Melange1pc1ch"][2] == -999999.0
+    assert np.allclose(df["amp2_of1x1_twice_Melange1pc1ch"][ok],
+                       2.0 * df["amp_of1x1_unconstrained_Melange1pc1ch"][ok], rtol=1e-6)
+    assert df["amp2_of1x1_twice_Melange1pc1ch"][2] == -999999.0
+    dup = tmp_path / "dup.py"
+    dup.write_text("class FeatureExtractors:\n    @staticmethod\n    def baseline(trace, **kw):\n"
+                   "        return {}\n")
+    with pytest.raises(ValueError, match="duplicate"):
+        FeatureProcessing(yaml_text, fd, CHANS, FS, external_file=str(dup))
+    with pytest.raises(ValueError, match="Cannot find algorithm"):
+        FeatureProcessing(yaml_text, fd, CHANS, FS).process(ev)
+
+
 @pytest.mark.gpu
 def test_feature_processing_from_adc_streams():
     """The YAML-driven batch driver on events cut from continuous int16 streams equals the
