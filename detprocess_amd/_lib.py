@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("OFX_LIB", os.path.join(_HERE, "libofx.so"))
 
 OK = 0
 MEM_HOST, MEM_DEVICE = 0, 1
-ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT = 0, 1, 2
+ENGINE_AUTO, ENGINE_FUSED, ENGINE_ROCFFT, ENGINE_LDS = 0, 1, 2, 3
 SEARCH_NODELAY, SEARCH_DELAY, SEARCH_DELAY_INTERP = 0, 1, 2
 SEARCH_FLOATS, TDWIN_FLOATS, BAND_FLOATS = 8, 8, 1
 MAX_SLOTS, MAX_SEARCHES, MAX_TDWIN, MAX_TERMS, MAX_BANDS = 8, 8, 8, 8, 16

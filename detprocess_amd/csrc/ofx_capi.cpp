@@ -103,6 +103,11 @@ extern "C" int ofx_plan_create(ofx_plan** out, int n_samples, int n_pretrigger,
                       n_samples);
         return OFX_ERR_UNSUPPORTED;
     }
+    if (engine == OFX_ENGINE_LDS && !ofx_lds_supported(n_samples)) {
+        ofx_set_error("ofx_plan_create: LDS engine does not support n_samples=%d (N/2 must be "
+                      "2^a 3^b 5^c and N <= 34816)", n_samples);
+        return OFX_ERR_UNSUPPORTED;
+    }
     OFX_HIP(hipSetDevice(device));
     hipDeviceProp_t prop;
     OFX_HIP(hipGetDeviceProperties(&prop, device));
@@ -116,7 +121,9 @@ extern "C" int ofx_plan_create(ofx_plan** out, int n_samples, int n_pretrigger,
     p->cu_count = prop.multiProcessorCount;
     if (engine == OFX_ENGINE_AUTO) {
         p->engine_auto = true;
-        engine = ofx_fused_supported(n_samples) ? OFX_ENGINE_FUSED : OFX_ENGINE_ROCFFT;
+        engine = ofx_fused_supported(n_samples) ? OFX_ENGINE_FUSED
+                 : ofx_lds_supported(n_samples) ? OFX_ENGINE_LDS
+                                                : OFX_ENGINE_ROCFFT;
     }
     p->engine = engine;
     p->chan[0] = 0;
@@ -153,6 +160,7 @@ extern "C" int ofx_plan_destroy(ofx_plan* p) {
     ofx_plan_reset(p);
     ofx_rocfft_release(p);
     ofx_fused_release(p);
+    ofx_lds_release(p);
     if (p->d_adc) (void)hipFree(p->d_adc);
     if (p->d_trig) (void)hipFree(p->d_trig);
     if (p->d_stage_in) (void)hipFree(p->d_stage_in);
@@ -406,6 +414,23 @@ static int ensure(float** buf, size_t* have, size_t want) {
     return OFX_OK;
 }
 
+// One engine call on device buffers.  AUTO plans fall back to the general engine when the
+// chosen fused engine reports that it cannot carry the plan (e.g. a lowchi2 cutoff or a
+// psd_amp band beyond the bins it stashes).
+static int engine_process(ofx_plan* p, const float* d_in, const uint8_t* d_valid, long long n,
+                          float* d_out, hipStream_t st) {
+    int rc;
+    if (p->engine == OFX_ENGINE_FUSED)
+        rc = ofx_fused_process(p, d_in, d_valid, n, d_out, st);
+    else if (p->engine == OFX_ENGINE_LDS)
+        rc = ofx_lds_process(p, d_in, d_valid, n, d_out, st);
+    else
+        return ofx_rocfft_process(p, d_in, d_valid, n, d_out, st);
+    if (rc == OFX_ERR_UNSUPPORTED && p->engine_auto)
+        rc = ofx_rocfft_process(p, d_in, d_valid, n, d_out, st);
+    return rc;
+}
+
 extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* valid,
                            long long n, int traces_mem, float* out, int out_mem,
                            void* stream) {
@@ -424,13 +449,7 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
     const size_t ev_floats = (size_t)p->n_channels * p->N;
 
     if (traces_mem == OFX_MEM_DEVICE && out_mem == OFX_MEM_DEVICE) {
-        if (p->engine == OFX_ENGINE_FUSED) {
-            const int rc = ofx_fused_process(p, traces, valid, n, out, st);
-            // AUTO: a plan the FUSED kernel cannot carry (lowchi2 cutoff or psd_amp band
-            // beyond its 512 stashed bins) runs on the general engine instead
-            if (rc != OFX_ERR_UNSUPPORTED || !p->engine_auto) return rc;
-        }
-        return ofx_rocfft_process(p, traces, valid, n, out, st);
+        return engine_process(p, traces, valid, n, out, st);
     }
 
     // host buffers on either side: stage chunk by chunk (PCIe-inclusive path)
@@ -464,11 +483,7 @@ extern "C" int ofx_process(ofx_plan* p, const float* traces, const uint8_t* vali
             if (rc) return rc;
             d_out = p->d_stage_out;
         }
-        int rc = (p->engine == OFX_ENGINE_FUSED)
-                     ? ofx_fused_process(p, d_in, d_valid, nb, d_out, st)
-                     : ofx_rocfft_process(p, d_in, d_valid, nb, d_out, st);
-        if (rc == OFX_ERR_UNSUPPORTED && p->engine == OFX_ENGINE_FUSED && p->engine_auto)
-            rc = ofx_rocfft_process(p, d_in, d_valid, nb, d_out, st);
+        int rc = engine_process(p, d_in, d_valid, nb, d_out, st);
         if (rc) return rc;
         if (out_mem == OFX_MEM_HOST) {
             OFX_HIP(hipMemcpyAsync(out + (size_t)b0 * row, d_out,
@@ -549,11 +564,7 @@ extern "C" int ofx_process_adc(ofx_plan* p, const int16_t* adc, long long n_stre
                             of.data(), p->d_stage_in, p->d_stage_valid, st);
         if (rc) return rc;
         float* d_out = (out_mem == OFX_MEM_HOST) ? p->d_stage_out : out + (size_t)b0 * row;
-        rc = (p->engine == OFX_ENGINE_FUSED)
-                 ? ofx_fused_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st)
-                 : ofx_rocfft_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st);
-        if (rc == OFX_ERR_UNSUPPORTED && p->engine == OFX_ENGINE_FUSED && p->engine_auto)
-            rc = ofx_rocfft_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st);
+        rc = engine_process(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st);
         if (rc) return rc;
         if (out_mem == OFX_MEM_HOST)
             OFX_HIP(hipMemcpyAsync(out + (size_t)b0 * row, d_out, (size_t)nb * row * sizeof(float),

@@ -139,6 +139,8 @@ struct ofx_plan {
     size_t adc_elems = 0;
     long long* d_trig = nullptr;
     size_t trig_elems = 0;
+    void* d_lds_tw = nullptr;            // LDS engine: twiddle table exp(-2 pi i j / N), slot table
+    void* d_lds_slots = nullptr;
     void* d_fused_slots = nullptr;       // FUSED multi-slot launches: slot table ...
     void* d_fused_spec = nullptr;        // ... and per-workgroup spectrum scratch
     size_t fused_spec_bytes = 0;
@@ -164,6 +166,10 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf);
 int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                       long long n, float* d_out, hipStream_t st);
 int ofx_fused_release(ofx_plan* p);
+bool ofx_lds_supported(int n_samples);
+int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
+                    long long n, float* d_out, hipStream_t st);
+int ofx_lds_release(ofx_plan* p);
 
 // timing helpers
 int ofx_time_begin(ofx_plan* p, hipStream_t st, size_t* idx);

@@ -16,7 +16,7 @@ from . import _lib
 from .filters import FilterTables
 
 _ENGINES = {"auto": _lib.ENGINE_AUTO, "fused": _lib.ENGINE_FUSED,
-            "rocfft": _lib.ENGINE_ROCFFT}
+            "rocfft": _lib.ENGINE_ROCFFT, "lds": _lib.ENGINE_LDS}
 
 
 def _torch():

@@ -38,7 +38,10 @@ enum { OFX_MEM_HOST = 0, OFX_MEM_DEVICE = 1 };
 /* engines: FUSED = one persistent LDS-resident FFT kernel per trace
  *          ROCFFT = rocFFT R2C -> filter kernel -> rocFFT C2R -> arg-max kernel
  *          AUTO = FUSED where the trace length is supported, else ROCFFT     */
-enum { OFX_ENGINE_AUTO = 0, OFX_ENGINE_FUSED = 1, OFX_ENGINE_ROCFFT = 2 };
+enum { OFX_ENGINE_AUTO = 0,     /* FUSED if n_samples == 32768, else LDS if it applies, else ROCFFT */
+       OFX_ENGINE_FUSED = 1,    /* register/LDS-resident kernel, n_samples == 32768            */
+       OFX_ENGINE_ROCFFT = 2,   /* rocFFT pipeline, any even n_samples                         */
+       OFX_ENGINE_LDS = 3 };    /* LDS-resident kernel, n_samples/2 = 2^a 3^b 5^c, <= 34816    */
 
 /* search kinds (one per of1x1 algorithm instance) */
 enum {
@@ -101,7 +104,7 @@ int ofx_plan_create(ofx_plan** plan, int n_samples, int n_pretrigger, double fs,
                     int max_batch, int device, int engine);
 int ofx_plan_destroy(ofx_plan* plan);
 
-/* which engine the plan resolved to (OFX_ENGINE_FUSED / OFX_ENGINE_ROCFFT). */
+/* which engine the plan resolved to (OFX_ENGINE_FUSED / OFX_ENGINE_LDS / OFX_ENGINE_ROCFFT). */
 int ofx_plan_engine(const ofx_plan* plan);
 
 /*

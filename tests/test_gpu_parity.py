@@ -30,7 +30,9 @@ def _run(plan, x32):
 
 
 @pytest.mark.parametrize("n,engine", [(32768, "fused"), (32768, "rocfft"), (4096, "rocfft"),
-                                      (8192, "rocfft"), (25000, "rocfft"), (1000, "rocfft")])
+                                      (8192, "rocfft"), (25000, "rocfft"), (1000, "rocfft"),
+                                      (32768, "lds"), (4096, "lds"), (8192, "lds"), (25000, "lds"),
+                                      (1000, "lds"), (30000, "lds"), (96, "lds")])
 @pytest.mark.parametrize("B", [1, 37])
 def test_unconstrained_vs_oracle(n, engine, B):
     plan, ft, filt, tmpl, psd = _mk(n, engine=engine, max_batch=16)
@@ -42,7 +44,8 @@ def test_unconstrained_vs_oracle(n, engine, B):
     check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, f"{n}/{engine}")
 
 
-@pytest.mark.parametrize("n,engine", [(32768, "fused"), (32768, "rocfft"), (4096, "rocfft")])
+@pytest.mark.parametrize("n,engine", [(32768, "fused"), (32768, "rocfft"), (4096, "rocfft"),
+                                      (25000, "lds"), (4096, "lds")])
 def test_interpolate_vs_oracle(n, engine):
     """interpolate=True (algorithms.py:357, 443): parabolic refinement around the discrete
     minimum, next to a plain search in the same plan; the refined t0 stays within half a
@@ -78,7 +81,7 @@ def test_interpolate_vs_oracle(n, engine):
     assert np.all(out[:, o1 + 2] <= out[:, plan.search_offset(0, s3) + 2] * (1 + 1e-6))
 
 
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "rocfft", "lds"])
 @pytest.mark.parametrize("pre", [7, 1000, 20001, 32760])
 def test_pretrigger_away_from_the_middle(engine, pre):
     """Rolled-index arithmetic (index = lag + pretrigger mod N) with the template onset
@@ -108,7 +111,7 @@ def test_pretrigger_away_from_the_middle(engine, pre):
                  ft.ampres, FS, f"pre{pre}/outside")
 
 
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "rocfft", "lds"])
 def test_three_template_slots_share_one_pass(engine):
     """BASELINE configs[3] shape: three template tags (pulse / glitch / muon) on one plan.
     The FUSED engine runs them in one launch on the shared forward transform; every slot
@@ -208,7 +211,7 @@ def test_auto_engine_falls_back_for_wide_lowchi2():
         _run(plan2, x32)
 
 
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "rocfft", "lds"])
 def test_all_search_kinds_and_lowchi2_cutoffs(engine):
     n = 32768
     plan, ft, filt, tmpl, psd = _mk(n, engine=engine)
@@ -231,7 +234,7 @@ def test_all_search_kinds_and_lowchi2_cutoffs(engine):
         check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, f"{engine}/{mode}")
 
 
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "rocfft", "lds"])
 def test_edge_cases(engine):
     """zero trace (every lag ties -> first rolled bin), constant trace (AC filter
     is blind to DC), single spike, invalid rows (-999999), empty batch."""
@@ -265,7 +268,7 @@ def test_edge_cases(engine):
     _ = snd, wid
 
 
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "rocfft", "lds"])
 def test_channel_algebra_on_load(engine):
     """'A+B' with weights and 'A-B' (processing_data.py:1033-1047)."""
     import torch

@@ -12,7 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # chi2     : |d| <= 2e-5 chi2 + 2e-6 chi2nopulse   (chi2 = chi0 - A^2 norm cancels at high SNR)
 # lowchi2  : |d| <= 2e-5 lowchi2 + 2e-6 chi2nopulse
 # t0       : the BIN must match exactly; the float value to 1e-6 relative
-# timeres  : 2e-5 relative ; ampres 1e-6 relative
+# timeres  : 2e-5 relative plus the relative error allowed on amp ; ampres 1e-6 relative
 AMP_RTOL, AMP_ATOL_SIGMA = 2e-5, 1e-4
 CHI_RTOL, CHI_ATOL_CHI0 = 2e-5, 2e-6
 
@@ -49,7 +49,10 @@ def check_search(out, off, ref, prefix, ampres, fs, what="", interpolated=False)
     if not np.all(np.isnan(chi0)):
         assert np.allclose(out[:, off + 4], chi0, rtol=CHI_RTOL), f"{what}: chi2nopulse"
         tr = g("timeres")
-        assert np.allclose(out[:, off + 6], tr, rtol=2e-5), f"{what}: timeres"
+        # timeres = 1 / sqrt(amp^2 tres_sum): inherits the relative error allowed on amp
+        rel = 2e-5 + (AMP_RTOL * np.abs(amp) + AMP_ATOL_SIGMA * ampres) / np.maximum(np.abs(amp), 1e-300)
+        bad = ~(np.abs(out[:, off + 6] - tr) <= rel * np.abs(tr))
+        assert not bad.any(), f"{what}: timeres {out[bad, off + 6]} vs {tr[bad]} (amp {amp[bad]})"
     assert np.allclose(out[:, off + 5], ampres, rtol=1e-6), f"{what}: ampres"
 
 
