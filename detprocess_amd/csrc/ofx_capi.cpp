@@ -121,8 +121,14 @@ extern "C" int ofx_plan_create(ofx_plan** out, int n_samples, int n_pretrigger,
     p->cu_count = prop.multiProcessorCount;
     if (engine == OFX_ENGINE_AUTO) {
         p->engine_auto = true;
+        // measured: the LDS engine wins wherever rocFFT needs several passes
+        // (lengths that are not powers of two) and for 4096..8192 samples; rocFFT's
+        // single-kernel power-of-two transforms win below and above that
+        const bool pow2 = (n_samples & (n_samples - 1)) == 0;
+        const bool lds_wins = ofx_lds_supported(n_samples) &&
+                              !(pow2 && (n_samples <= 2048 || n_samples >= 16384));
         engine = ofx_fused_supported(n_samples) ? OFX_ENGINE_FUSED
-                 : ofx_lds_supported(n_samples) ? OFX_ENGINE_LDS
+                 : lds_wins                     ? OFX_ENGINE_LDS
                                                 : OFX_ENGINE_ROCFFT;
     }
     p->engine = engine;
@@ -144,6 +150,7 @@ extern "C" int ofx_plan_reset(ofx_plan* p) {
     if (!p) return OFX_ERR_ARG;
     (void)hipSetDevice(p->device);
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) free_slot(p->slot[s]);
+    ++p->filter_stamp;
     p->tdwin.clear();
     p->bands.clear();
     p->n_channels = 1;
@@ -215,6 +222,8 @@ extern "C" int ofx_plan_set_filter(ofx_plan* p, int slot, const double* wf,
     h.norm = norm;
     h.tres_sum = tres_sum;
     h.g_host.assign(g, g + K);
+    h.wf_host.assign(wf, wf + 2 * (size_t)K);
+    ++p->filter_stamp;
     h.searches = keep;
     h.set = true;
     if (p->engine == OFX_ENGINE_FUSED) {
@@ -272,6 +281,7 @@ extern "C" int ofx_plan_add_search(ofx_plan* p, int slot, int kind, int lo, int 
         if (k * val <= fcut) nlow = k + 1; else break;
     q.nlow = nlow;
     h.searches.push_back(q);
+    ++p->filter_stamp;
     assign_offsets(p);
     return (int)h.searches.size() - 1;
 }

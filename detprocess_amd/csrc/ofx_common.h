@@ -90,6 +90,7 @@ struct OfxSlotHost {
     double norm = 0, tres_sum = 0;
     float wq_x = 0, wq_y = 0, gq = 0;   // fused engine: self-paired bin k = M/2
     std::vector<double> g_host;     // kept to count low-frequency bins
+    std::vector<double> wf_host;    // [2K] interleaved, kept for the LDS engine's pair tables
     std::vector<OfxSearchDev> searches;
 };
 
@@ -141,6 +142,10 @@ struct ofx_plan {
     size_t trig_elems = 0;
     void* d_lds_tw = nullptr;            // LDS engine: twiddle table exp(-2 pi i j / N), slot table
     void* d_lds_slots = nullptr;
+    void* d_lds_pos = nullptr;           // ... per-slot pair tables (LdsPair)
+    unsigned long long filter_stamp = 0; // bumped by set_filter / add_search / reset
+    unsigned long long lds_pair_stamp = ~0ull;
+    int lds_pair_slots = 0;
     void* d_fused_slots = nullptr;       // FUSED multi-slot launches: slot table ...
     void* d_fused_spec = nullptr;        // ... and per-workgroup spectrum scratch
     size_t fused_spec_bytes = 0;

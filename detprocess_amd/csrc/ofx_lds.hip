@@ -32,11 +32,24 @@ namespace {
 
 constexpr int LDS_MAX_FAC = 16;
 constexpr int LDS_VLOW = 1024;           // low bins of V kept in LDS (lowchi2 / psd_amp)
-constexpr size_t LDS_BUDGET = 150 * 1024;
+constexpr size_t LDS_BUDGET = 160 * 1024;
 
 struct LdsGeom {
     int M, N, nfac;
     int fac[LDS_MAX_FAC];
+    unsigned magic[LDS_MAX_FAC];   // floor(2^32 / stride) + 1 per stage: b / stride = umulhi(b, magic)
+    int toff[LDS_MAX_FAC];         // offset of the stage's twiddles W_L^j, j < stride, in the LDS table
+    int ntw;                       // entries of that table (sum of the strides > 1)
+};
+
+// middle-step constants of one bin pair (k, M - k), 48 bytes, built per slot on the host
+struct __attribute__((aligned(16))) LdsPair {
+    int pk, pp;            // positions of the two bins in the digit-reversed spectrum
+    float tx, ty;          // t_k = exp(-2 pi i k / N)
+    float wkx, wky;        // wf_k
+    float wpx, wpy;        // wf_p   (p = M - k; k = 0: the Nyquist bin)
+    float gk, gp;          // chi2 weights w g of the two bins (0 if the pair is one bin)
+    float pad0, pad1;
 };
 
 struct LdsSlot {
@@ -51,8 +64,10 @@ __device__ __forceinline__ cpx mul_i(cpx v) {
 
 // in-place radix-R DFT of x[0..R) with sign DIR (exp(DIR 2 pi i t q / R))
 template <int R, int DIR>
-__device__ __forceinline__ void dft_small(cpx (&x)[5]) {
-    if constexpr (R == 2) {
+__device__ __forceinline__ void dft_small(cpx (&x)[16]) {
+    if constexpr (R == 16 || R == 8) {
+        ofxfft::dft<R, DIR, 16, 0>(x);
+    } else if constexpr (R == 2) {
         const cpx a = x[0] + x[1], b = x[0] - x[1];
         x[0] = a; x[1] = b;
     } else if constexpr (R == 4) {
@@ -81,32 +96,59 @@ __device__ __forceinline__ void dft_small(cpx (&x)[5]) {
 
 // One stage over the whole array.  L: block length of the stage, r: radix, stride = L / r.
 // Forward (DIF): butterfly, then output q times W_L^{j q}.  Inverse: input q times
-// conj(W_L^{j q}), then inverse butterfly.  W_L^{e} = tw[e * (N / L)], e < L.
+// conj(W_L^{j q}), then inverse butterfly.  Only W_L^j is read, from per-stage tables copied
+// into LDS once per workgroup; the other powers are products (depth <= 5 for radix 16).
+template <int R>
+__device__ __forceinline__ void twiddle_powers(cpx (&w)[16], const cpx* tw1, int j) {
+    w[1] = tw1[j];
+    if constexpr (R > 2) w[2] = cmul(w[1], w[1]);
+    if constexpr (R > 3) w[3] = cmul(w[2], w[1]);
+    if constexpr (R > 4) {
+        w[4] = cmul(w[2], w[2]);
+    }
+    if constexpr (R > 5) {
+        w[5] = cmul(w[4], w[1]);
+        w[6] = cmul(w[4], w[2]);
+        w[7] = cmul(w[4], w[3]);
+    }
+    if constexpr (R > 8) {
+        w[8] = cmul(w[4], w[4]);
+        w[9] = cmul(w[8], w[1]);
+        w[10] = cmul(w[8], w[2]);
+        w[11] = cmul(w[8], w[3]);
+        w[12] = cmul(w[8], w[4]);
+        w[13] = cmul(w[12], w[1]);
+        w[14] = cmul(w[12], w[2]);
+        w[15] = cmul(w[12], w[3]);
+    }
+}
+
 template <int R, bool FWD>
-__device__ __forceinline__ void stage(cpx* z, const float2* __restrict__ tw, int M, int N, int L) {
+__device__ __forceinline__ void stage(cpx* z, const cpx* tw1, int M, int L,
+                                      unsigned magic) {
     const int stride = L / R;
-    const int tws = N / L;
     const int nbf = M / R;
     for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
-        const int blk = b / stride;
+        // exact for b, stride < 2^16 (M <= 17408)
+        const int blk = (stride == 1) ? b : (int)__umulhi((unsigned)b, magic);
         const int j = b - blk * stride;
         cpx* base = z + blk * L + j;
-        cpx x[5];
+        cpx x[16], w[16];
 #pragma unroll
         for (int t = 0; t < R; ++t) x[t] = base[t * stride];
+        const bool tw_needed = (stride > 1);          // last stage: every twiddle is 1
+        if (tw_needed) twiddle_powers<R>(w, tw1, j);
         if constexpr (!FWD) {
+            if (tw_needed) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) {
-                const float2 w = tw[(size_t)j * q * tws];
-                x[q] = cmulc(x[q], mk(w.x, w.y));
+                for (int q = 1; q < R; ++q) x[q] = cmulc(x[q], w[q]);
             }
         }
         dft_small<R, FWD ? -1 : 1>(x);
         if constexpr (FWD) {
+            if (tw_needed) {
 #pragma unroll
-            for (int q = 1; q < R; ++q) {
-                const float2 w = tw[(size_t)j * q * tws];
-                x[q] = cmul(x[q], mk(w.x, w.y));
+                for (int q = 1; q < R; ++q) x[q] = cmul(x[q], w[q]);
             }
         }
 #pragma unroll
@@ -115,15 +157,19 @@ __device__ __forceinline__ void stage(cpx* z, const float2* __restrict__ tw, int
 }
 
 template <bool FWD>
-__device__ __forceinline__ void stage_any(int r, cpx* z, const float2* tw, int M, int N, int L) {
-    if (r == 5) stage<5, FWD>(z, tw, M, N, L);
-    else if (r == 4) stage<4, FWD>(z, tw, M, N, L);
-    else if (r == 3) stage<3, FWD>(z, tw, M, N, L);
-    else stage<2, FWD>(z, tw, M, N, L);
+__device__ __forceinline__ void stage_any(int r, cpx* z, const cpx* tw1, int M, int L,
+                                          unsigned magic) {
+    if (r == 16) stage<16, FWD>(z, tw1, M, L, magic);
+    else if (r == 8) stage<8, FWD>(z, tw1, M, L, magic);
+    else if (r == 5) stage<5, FWD>(z, tw1, M, L, magic);
+    else if (r == 4) stage<4, FWD>(z, tw1, M, L, magic);
+    else if (r == 3) stage<3, FWD>(z, tw1, M, L, magic);
+    else stage<2, FWD>(z, tw1, M, L, magic);
 }
 
 // position of frequency bin k in the digit-reversed output of the forward transform
-__device__ __forceinline__ int pos_of(int k, const LdsGeom& g) {
+// (tabulated once per plan on the host)
+static int pos_of(int k, const LdsGeom& g) {
     int rem = k, p = 0, L = g.M;
     for (int i = 0; i < g.nfac; ++i) {
         const int r = g.fac[i];
@@ -135,30 +181,41 @@ __device__ __forceinline__ int pos_of(int k, const LdsGeom& g) {
     return p;
 }
 
-template <int BT>
+template <int BT, bool PF>
 __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsSlot* __restrict__ slots,
-                                            int nslots, const float2* __restrict__ tw,
+                                            int nslots, const float2* __restrict__ stw,
+                                            const LdsPair* __restrict__ pairs,
                                             const float* __restrict__ traces,
                                             const uint8_t* __restrict__ valid, long long n_traces,
                                             float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx* z = reinterpret_cast<cpx*>(smem);                         // [M]
     cpx* vlow = z + g.M;                                           // [LDS_VLOW]
-    float* scratch = reinterpret_cast<float*>(vlow + LDS_VLOW);    // [BT / 64]
+    cpx* tw1 = vlow + LDS_VLOW;                                    // [ntw] W_L^j per stage
+    float* scratch = reinterpret_cast<float*>(tw1 + g.ntw);        // [BT / 64]
     OfxCand* cscratch = reinterpret_cast<OfxCand*>(scratch + 32);  // [BT / 64]
     const int tid = threadIdx.x;
     const int M = g.M, N = g.N, pre = pd.pre;
     const float* a = reinterpret_cast<const float*>(z);            // lags after the inverse
+    for (int i = tid; i < g.ntw; i += BT) tw1[i] = mk(stw[i].x, stw[i].y);
 
+    // Software-pipelined trace load (when a trace fits NPF values per thread): the next
+    // trace is requested into registers before the searches of the current one, so its HBM
+    // latency hides under them -- with one workgroup per CU nothing else would.
+    constexpr int NPF = PF ? 34 : 1;
+    cpx pf[NPF];
+    bool have_pf = false;
+    const bool can_pf = PF && (M <= NPF * BT);
     for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
         float* row = out + (size_t)b * pd.row;
         if (valid && !valid[b]) {
             for (int j = tid; j < pd.row; j += BT) row[j] = OFX_SENTINEL;
+            have_pf = false;
             continue;
         }
-        const float* e = traces + (size_t)b * pd.n_channels * N;
         const bool plain = (pd.n_terms == 1 && pd.weight[0] == 1.0f);
-        auto sample2 = [&](int m) -> cpx {
+        auto sample2 = [&](long long bb, int m) -> cpx {
+            const float* e = traces + (size_t)bb * pd.n_channels * N;
             if (plain) {
                 const float2 v = reinterpret_cast<const float2*>(e + (size_t)pd.chan[0] * N)[m];
                 return mk(v.x, v.y);
@@ -173,7 +230,27 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
         const int pass_n = (nslots > 0) ? nslots : 1;
         for (int si = 0; si < pass_n; ++si) {
             __syncthreads();                       // previous readers of z are done
-            for (int m = tid; m < M; m += BT) z[m] = sample2(m);
+            if (si == 0 && have_pf) {
+                // the trace was requested during the previous event's searches
+#pragma unroll
+                for (int i = 0; i < NPF; ++i) {
+                    const int m = tid + i * BT;
+                    if (m < M) z[m] = pf[i];
+                }
+            } else if constexpr (PF) {
+                // cold start / extra slots: batches of independent loads, then the LDS writes
+                for (int m0 = tid; m0 < M; m0 += 8 * BT) {
+                    cpx tmp[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (m0 + i * BT < M) tmp[i] = sample2(b, m0 + i * BT);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (m0 + i * BT < M) z[m0 + i * BT] = tmp[i];
+                }
+            } else {
+                for (int m = tid; m < M; m += BT) z[m] = sample2(b, m);
+            }
             __syncthreads();
             // ---------------------------------------------- time-domain windows (once)
             if (si == 0) {
@@ -204,29 +281,36 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                         o[OFX_TD_LAST] = last;
                     }
                 }
-                if (nslots == 0 && pd.n_bands == 0) break;
+                if (nslots == 0 && pd.n_bands == 0) {
+                    have_pf = false;
+                    break;
+                }
                 __syncthreads();
             }
             // -------------------------------------------------------------- forward
             {
                 int L = M;
                 for (int i = 0; i < g.nfac; ++i) {
-                    stage_any<true>(g.fac[i], z, tw, M, N, L);
+                    stage_any<true>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
                     L /= g.fac[i];
                     __syncthreads();
                 }
             }
             // ------------------------------------------------ middle (k_mid algebra)
             const OfxSlotDev* sdp = (nslots > 0) ? &slots[si].sd : nullptr;
-            const float2* wf = sdp ? sdp->wf : nullptr;
-            const float* gg = sdp ? sdp->g : nullptr;
+            // pair table of this slot (slot 0's geometry part serves a plan without searches);
+            // the next pair's 48 bytes are requested before the current pair is worked on
+            const LdsPair* pt = pairs + (size_t)((nslots > 0) ? si : 0) * (M / 2 + 1);
             float acc = 0.0f;
+            LdsPair cur;
+            if (tid <= M / 2) cur = pt[tid];
+#pragma unroll 2
             for (int k = tid; k <= M / 2; k += BT) {
+                LdsPair nxt;
+                if (k + BT <= M / 2) nxt = pt[k + BT];
                 const int p = (k == 0) ? 0 : M - k;
-                const int pk = pos_of(k, g), pp = (p == k) ? pk : pos_of(p, g);
-                const cpx zk = z[pk], zp = z[pp];
-                const float2 t2 = tw[k];                                  // t_k = exp(-2 pi i k / N)
-                const float cs = t2.x, sn = t2.y;
+                const cpx zk = z[cur.pk], zp = z[cur.pp];
+                const float cs = cur.tx, sn = cur.ty;
                 cpx vk, vpc;
                 if (k == 0) {
                     vk = mk(zk.x + zk.y, 0.0f);
@@ -241,18 +325,18 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                 const int kp = (k == 0) ? M : p;
                 if (k < LDS_VLOW) vlow[k] = vk;
                 if (kp < LDS_VLOW && kp != k) vlow[kp] = mk(vpc.x, -vpc.y);
-                if (!wf) continue;
-                const float wk = (k == 0) ? 1.0f : 2.0f;
-                const float wp = (kp == M) ? 1.0f : 2.0f;
-                acc = fmaf(wk * gg[k], vk.x * vk.x + vk.y * vk.y, acc);
-                if (kp != k) acc = fmaf(wp * gg[kp], vpc.x * vpc.x + vpc.y * vpc.y, acc);
-                const float2 fa = wf[k], fc = wf[kp];
-                const cpx yk = mk(fa.x * vk.x - fa.y * vk.y, fa.x * vk.y + fa.y * vk.x);
-                const cpx ypc = mk(fc.x * vpc.x + fc.y * vpc.y, fc.x * vpc.y - fc.y * vpc.x);
-                const cpx ye = yk + ypc, d = yk - ypc;
-                const cpx yo = mk(d.x * cs + d.y * sn, d.y * cs - d.x * sn);
-                z[pk] = mk(ye.x - yo.y, ye.y + yo.x);
-                if (p != k) z[pp] = mk(ye.x + yo.y, -(ye.y - yo.x));
+                if (sdp) {
+                    acc = fmaf(cur.gk, vk.x * vk.x + vk.y * vk.y, acc);
+                    acc = fmaf(cur.gp, vpc.x * vpc.x + vpc.y * vpc.y, acc);
+                    const cpx yk = mk(cur.wkx * vk.x - cur.wky * vk.y, cur.wkx * vk.y + cur.wky * vk.x);
+                    const cpx ypc = mk(cur.wpx * vpc.x + cur.wpy * vpc.y,
+                                       cur.wpx * vpc.y - cur.wpy * vpc.x);
+                    const cpx ye = yk + ypc, d = yk - ypc;
+                    const cpx yo = mk(d.x * cs + d.y * sn, d.y * cs - d.x * sn);
+                    z[cur.pk] = mk(ye.x - yo.y, ye.y + yo.x);
+                    if (p != k) z[cur.pp] = mk(ye.x + yo.y, -(ye.y - yo.x));
+                }
+                cur = nxt;
             }
             __syncthreads();
             // psd_amp bands (first pass only)
@@ -270,7 +354,10 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     if (tid == 0) row[pd.band[i].out_off] = accb / (float)(hi - lo);
                 }
             }
-            if (!sdp) break;
+            if (!sdp) {
+                have_pf = false;
+                break;
+            }
             const float chi0 = ofx_block_sum(acc, scratch);
             // -------------------------------------------------------------- inverse
             {
@@ -281,8 +368,19 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     L /= g.fac[i];
                 }
                 for (int i = g.nfac - 1; i >= 0; --i) {
-                    stage_any<false>(g.fac[i], z, tw, M, N, Ls[i]);
+                    stage_any<false>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
                     __syncthreads();
+                }
+            }
+            if (si == pass_n - 1) {
+                const long long bn = b + gridDim.x;
+                have_pf = can_pf && (bn < n_traces) && !(valid && !valid[bn]);
+                if (have_pf) {
+#pragma unroll
+                    for (int i = 0; i < NPF; ++i) {
+                        const int m = tid + i * BT;
+                        if (m < M) pf[i] = sample2(bn, m);
+                    }
                 }
             }
             // ------------------------------------------------------------- searches
@@ -350,6 +448,8 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
 bool factorize(int M, std::vector<int>* fac) {
     fac->clear();
     int rem = M;
+    while (rem % 16 == 0) { fac->push_back(16); rem /= 16; }
+    while (rem % 8 == 0) { fac->push_back(8); rem /= 8; }
     while (rem % 5 == 0) { fac->push_back(5); rem /= 5; }
     while (rem % 4 == 0) { fac->push_back(4); rem /= 4; }
     while (rem % 3 == 0) { fac->push_back(3); rem /= 3; }
@@ -357,8 +457,18 @@ bool factorize(int M, std::vector<int>* fac) {
     return rem == 1 && (int)fac->size() <= LDS_MAX_FAC;
 }
 
-size_t lds_bytes_for(int M) {
-    return (size_t)M * 8 + (size_t)LDS_VLOW * 8 + 32 * 4 + 32 * sizeof(OfxCand);
+int stage_twiddle_count(int M, const std::vector<int>& fac) {
+    int L = M, n = 0;
+    for (int r : fac) {
+        if (L / r > 1) n += L / r;
+        L /= r;
+    }
+    return n;
+}
+
+size_t lds_bytes_for(int M, const std::vector<int>& fac) {
+    return (size_t)M * 8 + (size_t)LDS_VLOW * 8 + (size_t)stage_twiddle_count(M, fac) * 8 +
+           32 * 4 + 32 * sizeof(OfxCand);
 }
 
 }  // namespace
@@ -367,30 +477,31 @@ bool ofx_lds_supported(int n_samples) {
     if (n_samples < 16 || (n_samples % 2)) return false;
     std::vector<int> fac;
     if (!factorize(n_samples / 2, &fac)) return false;
-    return lds_bytes_for(n_samples / 2) <= LDS_BUDGET;
+    return lds_bytes_for(n_samples / 2, fac) <= LDS_BUDGET;
 }
 
 int ofx_lds_release(ofx_plan* p) {
     if (p->d_lds_tw) (void)hipFree(p->d_lds_tw);
     if (p->d_lds_slots) (void)hipFree(p->d_lds_slots);
+    if (p->d_lds_pos) (void)hipFree(p->d_lds_pos);
+    p->d_lds_pos = nullptr;
     p->d_lds_tw = nullptr;
     p->d_lds_slots = nullptr;
     return OFX_OK;
 }
 
-template <int BT>
+template <int BT, bool PF>
 static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int nslots,
                       const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
-                      hipStream_t st) {
-    const size_t lds = lds_bytes_for(g.M);
+                      hipStream_t st, size_t lds) {
     static size_t attr_done = 0;
     if (attr_done < lds) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT>),
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT, PF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
         attr_done = LDS_BUDGET;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    const int by_threads = 2048 / BT;
+    const int by_threads = 1024 / BT;
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)p->cu_count * per_cu;
@@ -398,9 +509,10 @@ static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int n
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lds<BT>, dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
+    hipLaunchKernelGGL((k_lds<BT, PF>), dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
                        reinterpret_cast<const LdsSlot*>(p->d_lds_slots), nslots,
-                       reinterpret_cast<const float2*>(p->d_lds_tw), d_traces, d_valid, n, d_out);
+                       reinterpret_cast<const float2*>(p->d_lds_tw),
+                       reinterpret_cast<const LdsPair*>(p->d_lds_pos), d_traces, d_valid, n, d_out);
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
@@ -411,7 +523,7 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
                     float* d_out, hipStream_t st) {
     const int N = p->N, M = N / 2;
     std::vector<int> fac;
-    if (!factorize(M, &fac) || lds_bytes_for(M) > LDS_BUDGET) {
+    if (!factorize(M, &fac) || lds_bytes_for(M, fac) > LDS_BUDGET) {
         ofx_set_error("LDS engine: n_samples=%d is not supported", N);
         return OFX_ERR_UNSUPPORTED;
     }
@@ -422,13 +534,35 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     g.M = M;
     g.N = N;
     g.nfac = (int)fac.size();
-    for (int i = 0; i < g.nfac; ++i) g.fac[i] = fac[i];
+    {
+        int L = M;
+        for (int i = 0; i < g.nfac; ++i) {
+            g.fac[i] = fac[i];
+            const unsigned stride = (unsigned)(L / fac[i]);
+            g.magic[i] = (unsigned)((1ull << 32) / stride) + 1u;     // unused when stride == 1
+            g.toff[i] = g.ntw;
+            if (stride > 1) g.ntw += (int)stride;
+            L /= fac[i];
+        }
+    }
+    const double c0 = -6.283185307179586476925286766559 / (double)N;
     if (!p->d_lds_tw) {
-        std::vector<float2> tw(N);
-        const double c = -6.283185307179586476925286766559 / (double)N;
-        for (int j = 0; j < N; ++j) tw[j] = make_float2((float)std::cos(c * j), (float)std::sin(c * j));
-        OFX_HIP(hipMalloc(&p->d_lds_tw, sizeof(float2) * (size_t)N));
-        OFX_HIP(hipMemcpy(p->d_lds_tw, tw.data(), sizeof(float2) * (size_t)N, hipMemcpyHostToDevice));
+        // per-stage twiddles W_L^j, j < stride (stages with stride 1 have none)
+        std::vector<float2> t1((size_t)g.ntw);
+        int L = M;
+        for (int i = 0; i < g.nfac; ++i) {
+            const int stride = L / g.fac[i];
+            if (stride > 1)
+                for (int j = 0; j < stride; ++j) {
+                    const double a1 = c0 * 2.0 * (double)j * (double)(M / L);       // W_L^j
+                    t1[g.toff[i] + j] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+                }
+            L /= g.fac[i];
+        }
+        OFX_HIP(hipMalloc(&p->d_lds_tw, sizeof(float2) * std::max<size_t>(1, t1.size())));
+        if (!t1.empty())
+            OFX_HIP(hipMemcpy(p->d_lds_tw, t1.data(), sizeof(float2) * t1.size(),
+                              hipMemcpyHostToDevice));
     }
     std::vector<LdsSlot> args;
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
@@ -451,11 +585,64 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
             return OFX_ERR_UNSUPPORTED;
         }
     const int nslots = (int)args.size();
+    {
+        // pair tables: geometry + the slot's filter; rebuilt when the plan's filters changed
+        const int np = M / 2 + 1;
+        const int ntab = std::max(1, nslots);
+        if (p->lds_pair_stamp != p->filter_stamp || p->lds_pair_slots != ntab || !p->d_lds_pos) {
+            std::vector<LdsPair> tab((size_t)ntab * np);
+            int si = 0;
+            for (int s = 0; s < OFX_MAX_SLOTS || si == 0; ++s) {
+                const bool have = s < OFX_MAX_SLOTS && p->slot[s].set && !p->slot[s].searches.empty();
+                if (s < OFX_MAX_SLOTS && !have && !(nslots == 0 && s == 0)) continue;
+                for (int k = 0; k < np; ++k) {
+                    const int pidx = (k == 0) ? 0 : M - k;
+                    const int kp = (k == 0) ? M : pidx;
+                    LdsPair& e = tab[(size_t)si * np + k];
+                    memset(&e, 0, sizeof(e));
+                    e.pk = pos_of(k, g);
+                    e.pp = pos_of(pidx, g);
+                    e.tx = (float)std::cos(c0 * k);
+                    e.ty = (float)std::sin(c0 * k);
+                    if (have) {
+                        const OfxSlotHost& h = p->slot[s];
+                        e.wkx = (float)h.wf_host[2 * k];
+                        e.wky = (float)h.wf_host[2 * k + 1];
+                        e.wpx = (float)h.wf_host[2 * kp];
+                        e.wpy = (float)h.wf_host[2 * kp + 1];
+                        e.gk = (float)(((k == 0) ? 1.0 : 2.0) * h.g_host[k]);
+                        e.gp = (kp == k) ? 0.0f : (float)(((kp == M) ? 1.0 : 2.0) * h.g_host[kp]);
+                    }
+                }
+                ++si;
+                if (si >= ntab) break;
+            }
+            if (p->d_lds_pos) (void)hipFree(p->d_lds_pos);
+            p->d_lds_pos = nullptr;
+            OFX_HIP(hipMalloc(&p->d_lds_pos, sizeof(LdsPair) * tab.size()));
+            OFX_HIP(hipMemcpy(p->d_lds_pos, tab.data(), sizeof(LdsPair) * tab.size(),
+                              hipMemcpyHostToDevice));
+            p->lds_pair_stamp = p->filter_stamp;
+            p->lds_pair_slots = ntab;
+        }
+    }
     if (nslots > 0) {
         if (!p->d_lds_slots) OFX_HIP(hipMalloc(&p->d_lds_slots, sizeof(LdsSlot) * OFX_MAX_SLOTS));
         OFX_HIP(hipMemcpyAsync(p->d_lds_slots, args.data(), sizeof(LdsSlot) * (size_t)nslots,
                                hipMemcpyHostToDevice, st));
     }
-    if (M >= 8192) return launch_lds<512>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st);
-    return launch_lds<256>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st);
+    // about one widest butterfly per thread and stage
+    const int bf = M / fac[0];
+    const size_t lds = lds_bytes_for(M, fac);
+    // the register prefetch of the next trace pays when only one workgroup fits a CU
+    // (nothing else hides the HBM latency); with many small workgroups it only costs occupancy
+    const bool pf = lds > 80 * 1024;
+    if (bf >= 1024)
+        return pf ? launch_lds<512, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds)
+                  : launch_lds<512, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+    if (bf >= 256)
+        return pf ? launch_lds<256, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds)
+                  : launch_lds<256, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+    if (bf >= 128) return launch_lds<128, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+    return launch_lds<64, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
 }
