@@ -447,13 +447,15 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
 
 bool factorize(int M, std::vector<int>* fac) {
     fac->clear();
+    // even radices first, odd ones last: the late stages (small strides, lanes spread over
+    // many blocks) then step through LDS with odd strides and stay free of bank conflicts
     int rem = M;
     while (rem % 16 == 0) { fac->push_back(16); rem /= 16; }
     while (rem % 8 == 0) { fac->push_back(8); rem /= 8; }
-    while (rem % 5 == 0) { fac->push_back(5); rem /= 5; }
     while (rem % 4 == 0) { fac->push_back(4); rem /= 4; }
-    while (rem % 3 == 0) { fac->push_back(3); rem /= 3; }
     while (rem % 2 == 0) { fac->push_back(2); rem /= 2; }
+    while (rem % 5 == 0) { fac->push_back(5); rem /= 5; }
+    while (rem % 3 == 0) { fac->push_back(3); rem /= 3; }
     return rem == 1 && (int)fac->size() <= LDS_MAX_FAC;
 }
 
@@ -637,7 +639,7 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     // the register prefetch of the next trace pays when only one workgroup fits a CU
     // (nothing else hides the HBM latency); with many small workgroups it only costs occupancy
     const bool pf = lds > 80 * 1024;
-    if (bf >= 1024)
+    if (bf >= 1024 || pf)        // one workgroup per CU: give it eight waves
         return pf ? launch_lds<512, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds)
                   : launch_lds<512, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
     if (bf >= 256)
