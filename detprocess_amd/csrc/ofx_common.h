@@ -146,6 +146,9 @@ struct ofx_plan {
     unsigned long long filter_stamp = 0; // bumped by set_filter / add_search / reset
     unsigned long long lds_pair_stamp = ~0ull;
     int lds_pair_slots = 0;
+    unsigned long long lds_slot_stamp = ~0ull, fused_slot_stamp = ~0ull;
+    std::vector<unsigned char> h_slot_args;   // host copy of the slot table of the last launch
+                                              // (kept alive: the upload is asynchronous)
     void* d_fused_slots = nullptr;       // FUSED multi-slot launches: slot table ...
     void* d_fused_spec = nullptr;        // ... and per-workgroup spectrum scratch
     size_t fused_spec_bytes = 0;

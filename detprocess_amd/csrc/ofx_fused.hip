@@ -1276,12 +1276,19 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
         return launch_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, nullptr,
                                   nslots);
     }
-    // several slots: upload the slot table (the copy from pageable memory is staged
-    // before the call returns, so the host vector may die with this frame)
+    // several slots: upload the slot table (from a buffer owned by the plan: the copy is
+    // asynchronous on the stream)
     const size_t bytes = sizeof(FusedSlotArg) * (size_t)nslots;
     if (!p->d_fused_slots)
         OFX_HIP(hipMalloc(&p->d_fused_slots, sizeof(FusedSlotArg) * OFX_MAX_SLOTS));
-    OFX_HIP(hipMemcpyAsync(p->d_fused_slots, args.data(), bytes, hipMemcpyHostToDevice, st));
+    if (p->fused_slot_stamp != p->filter_stamp) {
+        OFX_HIP(hipStreamSynchronize(st));      // an earlier launch may still read the table
+        p->h_slot_args.assign(reinterpret_cast<const unsigned char*>(args.data()),
+                              reinterpret_cast<const unsigned char*>(args.data()) + bytes);
+        OFX_HIP(hipMemcpyAsync(p->d_fused_slots, p->h_slot_args.data(), bytes,
+                               hipMemcpyHostToDevice, st));
+        p->fused_slot_stamp = p->filter_stamp;
+    }
     OfxSlotDev sd0;
     memset(&sd0, 0, sizeof(sd0));
     return launch_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,

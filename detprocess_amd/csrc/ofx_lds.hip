@@ -630,8 +630,15 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     }
     if (nslots > 0) {
         if (!p->d_lds_slots) OFX_HIP(hipMalloc(&p->d_lds_slots, sizeof(LdsSlot) * OFX_MAX_SLOTS));
-        OFX_HIP(hipMemcpyAsync(p->d_lds_slots, args.data(), sizeof(LdsSlot) * (size_t)nslots,
-                               hipMemcpyHostToDevice, st));
+        if (p->lds_slot_stamp != p->filter_stamp) {
+            OFX_HIP(hipStreamSynchronize(st));  // an earlier launch may still read the table
+            const size_t bytes = sizeof(LdsSlot) * (size_t)nslots;
+            p->h_slot_args.assign(reinterpret_cast<const unsigned char*>(args.data()),
+                                  reinterpret_cast<const unsigned char*>(args.data()) + bytes);
+            OFX_HIP(hipMemcpyAsync(p->d_lds_slots, p->h_slot_args.data(), bytes,
+                                   hipMemcpyHostToDevice, st));
+            p->lds_slot_stamp = p->filter_stamp;
+        }
     }
     // about one widest butterfly per thread and stage
     const int bf = M / fac[0];
