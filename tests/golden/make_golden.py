@@ -58,7 +58,38 @@ def make(n_samples, n_traces, seed, pre=None, fname=None):
     print(fname, "written:", n_traces, "x", n_samples)
 
 
+def make_trigger(fname="golden_trigger_n4096.npz"):
+    """Continuous-data trigger (oracle/oftrigger.py): a 120k-sample stream with noise and
+    pulses, the filtered / delta-chi2 traces at a few probe points and the triggers for
+    two pile-up windows."""
+    from oracle import oftrigger as ot
+    n, pre, L = 4096, 1500, 120000
+    rng = np.random.default_rng(2024)
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    t = ot.OFTrigger(FS, tmpl, psd, pre)
+    x = synth.coloured_noise(rng, L // n + 2, psd, FS).reshape(-1)[:L]
+    onsets = np.sort(rng.integers(2 * n, L - 3 * n, 9))
+    amps = t.resolution * rng.uniform(10, 60, 9)
+    for p, a in zip(onsets, amps):
+        x[p:p + n] += a * tmpl
+    x32 = x.astype(np.float32)
+    filt, dchi = t.update_trace(x32.astype(np.float64))
+    out = {"template": tmpl, "psd": psd, "fs": FS, "pre": pre, "stream": x32,
+           "onsets": onsets, "amps": amps, "probe": np.arange(0, L, 997),
+           "filtered_probe": filt[::997], "dchi2_probe": dchi[::997],
+           "filtered_max": np.max(np.abs(filt)), "dchi2_max": np.max(dchi)}
+    for w in (200, 8192):
+        r = t.find_triggers(5.0, pileup_window_samples=w)
+        for k in ("trigger_index", "trigger_delta_chi2", "trigger_amplitude"):
+            out[f"w{w}_{k}"] = r[k]
+        out[f"w{w}_chi2_threshold"] = r["chi2_threshold"]
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written")
+
+
 if __name__ == "__main__":
+    make_trigger()
     make(4096, 32, seed=41, fname="golden_n4096.npz")
     make(4096, 8, seed=42, pre=1000, fname="golden_n4096_pre1000.npz")
     make(32768, 6, seed=43, fname="golden_n32768.npz")

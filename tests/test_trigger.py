@@ -126,3 +126,55 @@ def test_gpu_trigger_vs_oracle(n, pre, L):
     g.update_trace(adc, adc_scale=sc)
     t.update_trace(adc.astype(np.float64) * np.float32(sc))
     assert np.max(np.abs(g.get_filtered_trace()[0] - t.filtered)) <= 2e-5 * scale
+
+
+def _load_trigger_golden():
+    from util import load_golden
+    return load_golden("golden_trigger_n4096.npz")
+
+
+def test_oracle_reproduces_trigger_golden():
+    g = _load_trigger_golden()
+    t = ot.OFTrigger(float(g["fs"]), g["template"], g["psd"], int(g["pre"]))
+    filt, dchi = t.update_trace(g["stream"].astype(np.float64))
+    assert np.allclose(filt[::997], g["filtered_probe"], rtol=1e-12, atol=0)
+    assert np.allclose(dchi[::997], g["dchi2_probe"], rtol=1e-12, atol=0)
+    for w in (200, 8192):
+        r = t.find_triggers(5.0, pileup_window_samples=w)
+        assert np.array_equal(r["trigger_index"], g[f"w{w}_trigger_index"])
+        assert np.allclose(r["trigger_amplitude"], g[f"w{w}_trigger_amplitude"], rtol=1e-12)
+    # every isolated injected pulse is among the triggers (one sample late, see the oracle)
+    found = [int(i) for i in g["w200_trigger_index"]]
+    onsets = [int(p) for p in g["onsets"]]
+    n = g["template"].shape[0]
+    for p in onsets:
+        if min(abs(p - o) for o in onsets if o != p) > 2 * n:
+            assert any(abs(p + int(g["pre"]) + 1 - f) <= 2 for f in found)
+
+
+@pytest.mark.gpu
+def test_gpu_trigger_reproduces_golden():
+    from detprocess_amd import OptimumFilterTrigger
+    g = _load_trigger_golden()
+    fs, pre = float(g["fs"]), int(g["pre"])
+    trig = OptimumFilterTrigger("chanA", fs, g["template"], g["psd"], pre)
+    trig.update_trace(g["stream"])
+    f = trig.get_filtered_trace()[0].astype(np.float64)
+    d = trig.get_filtered_delta_chi2().astype(np.float64)
+    assert np.max(np.abs(f[::997] - g["filtered_probe"])) <= 2e-5 * float(g["filtered_max"])
+    assert np.max(np.abs(d[::997] - g["dchi2_probe"])) <= 4e-5 * float(g["dchi2_max"])
+    for w in (200, 8192):
+        trig.find_triggers(5.0, pileup_window_samples=w)
+        td = trig.get_trigger_data()["chanA"]
+        thr = float(g[f"w{w}_chi2_threshold"])
+        margin = 1e-3 * thr + 4e-5 * float(g["dchi2_max"])
+        want = {int(i): (dc, a) for i, dc, a in zip(g[f"w{w}_trigger_index"],
+                                                    g[f"w{w}_trigger_delta_chi2"],
+                                                    g[f"w{w}_trigger_amplitude"])}
+        got = {int(i): (dc, a) for i, dc, a in zip(td["trigger_index"], td["trigger_delta_chi2"],
+                                                   td["trigger_amplitude"])}
+        clear = {i for i, (dc, a) in want.items() if dc > thr + margin}
+        assert clear <= set(got)
+        assert {i for i, (dc, a) in got.items() if dc > thr + margin} <= set(want)
+        for i in set(want) & set(got):
+            assert got[i][1] == pytest.approx(want[i][1], rel=2e-5, abs=2e-5 * float(g["filtered_max"]))
