@@ -94,8 +94,13 @@ class FeatureProcessing:
         return fe_ext, names
 
     # ----------------------------------------------------------------- compile
-    def _compile(self, n_samples):
+    def _compile(self, n_samples, from_streams=False):
+        """One plan per (channel, nb_samples, nb_pretrigger_samples) -- the reference's
+        OF-base key (features.py:794-823; config.py:547-572 lets every algorithm carry its own
+        trace length).  Float events have one length, so there every algorithm must agree
+        with it; events cut from raw streams (``process_adc``) are cut per plan."""
         plans = {}
+        default_n = n_samples
         weights_all = self._config.get("weights", {})
         for channel, algorithms in self._config["channels"].items():
             if not isinstance(algorithms, dict):
@@ -118,186 +123,188 @@ class FeatureProcessing:
                 if len(names) != 2:
                     raise ValueError('ERROR: "-" needs exactly two channels')
                 w[1] = -w[1]
-            cp = _ChannelPlan()
-            slots = {}
-            td_windows = {}
-            pending = []
-            nb_pre_plan = None
+            # group the running algorithms by their (nb_samples, nb_pretrigger_samples)
+            groups = {}
             for algorithm, params in algorithms.items():
                 if not isinstance(params, dict) or not params.get("run", False):
                     continue
-                base = params.get("base_algorithm", algorithm)
-                nb = params.get("nb_samples") or self._nb_samples or n_samples
+                nb = params.get("nb_samples") or self._nb_samples or default_n
                 npre = params.get("nb_pretrigger_samples")
                 if npre is None:
                     npre = self._nb_pretrigger if self._nb_pretrigger is not None else nb // 2
-                if nb != n_samples:
+                if not from_streams and nb != default_n:
                     raise ValueError(f"ERROR: Number of samples is not consistent between "
-                                     f"raw data (={n_samples}) and algorithm {algorithm} "
+                                     f"raw data (={default_n}) and algorithm {algorithm} "
                                      f"(={nb}) for channel {channel}!")
-                kwargs = {k: v for k, v in params.items() if k != "run"}
-                kwargs["fs"] = self._fs
-                kwargs.setdefault("nb_samples", nb)
-                kwargs.setdefault("nb_pretrigger_samples", npre)
-                kwargs["nb_samples"], kwargs["nb_pretrigger_samples"] = nb, npre
-                wmin, wmax = utils.get_window_indices(**kwargs)
-                if nb_pre_plan is None:
-                    nb_pre_plan = npre
-                if base in OF_ALGORITHMS:
-                    if npre != nb_pre_plan:
-                        raise ValueError("ERROR: one pretrigger length per feature channel")
-                    if "template_tag" not in params:
-                        raise ValueError(f'ERROR: a "template_tag" in yaml file is required '
-                                         f'for channel {channel}, algorithm "{algorithm}" !')
-                    csd_tag = params.get("csd_tag", "default")
-                    coupling = params.get("coupling", "AC")
-                    peaks = params.get("ignored_frequency_peaks")
-                    if peaks is not None and not isinstance(peaks, list):
-                        peaks = [peaks]
-                    harm = bool(params.get("ignore_harmonics", False)) if peaks else False
-                    skey = (params["template_tag"], csd_tag, coupling,
-                            tuple(peaks) if peaks else None, harm,
-                            bool(params.get("integralnorm", False)))
-                    pending.append(("of", algorithm, base, skey, params, wmin, wmax, npre))
-                elif base in TD_ALGORITHMS:
-                    pending.append(("td", algorithm, base, None, params, wmin, wmax, npre))
-                elif base == "energyabsorbed":
-                    for key in ("vb", "i0", "rl"):
-                        if key not in params:
-                            raise ValueError(f'ERROR: energyabsorbed requires "{key}" '
-                                             f"(channel {channel})")
-                    pending.append(("energy", algorithm, base, None, params, wmin, wmax, npre))
-                elif base == "psd_amp":
-                    if not params.get("f_lims"):
-                        raise ValueError('ERROR: "f_lims" required for algorithm psd_amps')
-                    pending.append(("band", algorithm, base, None, params, wmin, wmax, npre))
-                elif base in self._ext_names:
-                    # user algorithm (features.py:749-752): same injected kwargs as built-ins
-                    kw = dict(kwargs)
-                    kw["window_min_index"], kw["window_max_index"] = wmin, wmax
-                    kw["feature_base_name"] = algorithm
-                    cp.external.append((algorithm, base, kw, params,
-                                        any(p in base for p in OF_BASE_PREFIXES)))
-                elif any(p in base for p in OF_BASE_PREFIXES):
-                    raise NotImplementedError(
-                        f'algorithm "{base}" is outside the of1x1 hot path of this engine')
-                else:
-                    raise ValueError(f'ERROR: Cannot find algorithm "{base}" anywhere. '
-                                     f"Check feature extractor exists!")
-            cp.channel, cp.feature_channel = channel, feature_channel
-            cp.chan_index, cp.chan_weight, cp.chan_names = idx, w, names
-            if not pending:
-                if cp.external:
-                    plans[channel] = cp
-                continue
-            # psd_amp bands ride on a filter slot in the FUSED engine (and only the
-            # lowest bins); otherwise the general ROCFFT engine carries them
-            engine = self._engine
-            bands = [x for x in pending if x[0] == "band"]
-            if bands and engine != "rocfft":
-                has_of = any(x[0] == "of" for x in pending)
-                kmax = 0
-                for x in bands:
-                    rng, _ = utils.cleanup_freq_ranges(x[4]["f_lims"])
-                    kmax = max([kmax] + [hi for _, hi in utils.get_bin_ranges(rng, n_samples,
-                                                                              self._fs)])
-                if not has_of or kmax > FUSED_MAX_BAND_BIN:
-                    engine = "rocfft"
-            plan = OFPlan(n_samples, nb_pre_plan, self._fs, max_batch=self._max_batch,
-                          device=self._device, engine=engine)
-            if len(self._channels) > 1 or len(idx) > 1 or w[0] != 1.0:
-                plan.set_channels(len(self._channels), idx, w)
-            cols = []
-            for kind, algorithm, base, skey, params, wmin, wmax, npre in pending:
-                if kind == "of":
-                    if skey not in slots:
-                        slot = len(slots)
-                        tag, csd_tag, coupling, peaks, harm, inorm = skey
-                        # filter lookup uses the first physical channel of the expression
-                        fchan = channel if channel in self._filter_data._filter_data else names[0]
-                        template, _, tmeta = self._filter_data.get_template(
-                            fchan, tag=tag, return_metadata=True)
-                        csd, _, cmeta = self._filter_data.get_csd(
-                            fchan, tag=csd_tag, fold=False, return_metadata=True)
-                        if "sample_rate" in cmeta and cmeta["sample_rate"] != self._fs:
-                            raise ValueError(f"Sample rate is not consistent between raw "
-                                             f"data and csd for channel {channel}!")
-                        if n_samples != csd.shape[-1]:
-                            raise ValueError(
-                                f"Number of samples is not consistent between raw data "
-                                f"(={n_samples}) and csd (={csd.shape[-1]})for channel "
-                                f"{channel}, algorithm {algorithm}!")
-                        if n_samples != template.shape[-1]:
-                            raise ValueError(
-                                f'Number of samples is not consistent between raw data and '
-                                f'template ("{tag}") for channel {channel}, algorithm '
-                                f"{algorithm}!")
-                        pre_t = int(tmeta.get("nb_pretrigger_samples", npre))
-                        if pre_t != nb_pre_plan:
-                            raise ValueError("ERROR: template pretrigger differs from the "
-                                             "trace pretrigger")
-                        tables = build_filter(template, csd, self._fs, pre_t, coupling,
-                                              list(peaks) if peaks else None, harm, inorm)
-                        plan.set_filter(slot, tables)
-                        slots[skey] = slot
-                    slot = slots[skey]
-                    skind, qtys = OF_ALGORITHMS[base]
-                    fcut = float(params.get("lowchi2_fcutoff", 10000))
-                    interp = bool(params.get("interpolate", False)) and skind == "delay"
-                    if base == "of1x1_constrained":
-                        lo, hi = search_range(n_samples, nb_pre_plan, self._fs,
-                                              params.get("window_min_from_trig_usec"),
-                                              params.get("window_max_from_trig_usec"),
-                                              wmin, wmax, self._policy)
-                        sid = plan.add_search(slot, "delay", lo, hi,
-                                              bool(params.get("lgc_outside_window", False)),
-                                              fcut, interp)
+                groups.setdefault((int(nb), int(npre)), {})[algorithm] = params
+            for (n_samples, nb_pre_plan), algorithms in groups.items():
+                cp = _ChannelPlan()
+                slots = {}
+                td_windows = {}
+                pending = []
+                for algorithm, params in algorithms.items():
+                    base = params.get("base_algorithm", algorithm)
+                    nb, npre = n_samples, nb_pre_plan
+                    kwargs = {k: v for k, v in params.items() if k != "run"}
+                    kwargs["fs"] = self._fs
+                    kwargs.setdefault("nb_samples", nb)
+                    kwargs.setdefault("nb_pretrigger_samples", npre)
+                    kwargs["nb_samples"], kwargs["nb_pretrigger_samples"] = nb, npre
+                    wmin, wmax = utils.get_window_indices(**kwargs)
+                    if base in OF_ALGORITHMS:
+                        if "template_tag" not in params:
+                            raise ValueError(f'ERROR: a "template_tag" in yaml file is required '
+                                             f'for channel {channel}, algorithm "{algorithm}" !')
+                        csd_tag = params.get("csd_tag", "default")
+                        coupling = params.get("coupling", "AC")
+                        peaks = params.get("ignored_frequency_peaks")
+                        if peaks is not None and not isinstance(peaks, list):
+                            peaks = [peaks]
+                        harm = bool(params.get("ignore_harmonics", False)) if peaks else False
+                        skey = (params["template_tag"], csd_tag, coupling,
+                                tuple(peaks) if peaks else None, harm,
+                                bool(params.get("integralnorm", False)))
+                        pending.append(("of", algorithm, base, skey, params, wmin, wmax, npre))
+                    elif base in TD_ALGORITHMS:
+                        pending.append(("td", algorithm, base, None, params, wmin, wmax, npre))
+                    elif base == "energyabsorbed":
+                        for key in ("vb", "i0", "rl"):
+                            if key not in params:
+                                raise ValueError(f'ERROR: energyabsorbed requires "{key}" '
+                                                 f"(channel {channel})")
+                        pending.append(("energy", algorithm, base, None, params, wmin, wmax, npre))
+                    elif base == "psd_amp":
+                        if not params.get("f_lims"):
+                            raise ValueError('ERROR: "f_lims" required for algorithm psd_amps')
+                        pending.append(("band", algorithm, base, None, params, wmin, wmax, npre))
+                    elif base in self._ext_names:
+                        # user algorithm (features.py:749-752): same injected kwargs as built-ins
+                        kw = dict(kwargs)
+                        kw["window_min_index"], kw["window_max_index"] = wmin, wmax
+                        kw["feature_base_name"] = algorithm
+                        cp.external.append((algorithm, base, kw, params,
+                                            any(p in base for p in OF_BASE_PREFIXES)))
+                    elif any(p in base for p in OF_BASE_PREFIXES):
+                        raise NotImplementedError(
+                            f'algorithm "{base}" is outside the of1x1 hot path of this engine')
                     else:
-                        sid = plan.add_search(slot, skind, lowchi2_fcutoff=fcut,
-                                              interpolate=interp)
-                    cols.append(("of", slot, sid, qtys, algorithm))
-                elif kind == "band":
-                    rng, rnames = utils.cleanup_freq_ranges(params["f_lims"])
-                    for (klo, khi), rname in zip(utils.get_bin_ranges(rng, n_samples, self._fs),
-                                                 rnames):
-                        cols.append(("band", plan.add_band(klo, khi), f"{algorithm}_{rname}"))
-                elif kind == "energy":
-                    if wmin < 1:
-                        raise ValueError("ERROR: energyabsorbed needs a window starting after "
-                                         "sample 0 (its baseline is mean(trace[:window_min]))")
-                    for key in ((0, wmin), (wmin, wmax)):
+                        raise ValueError(f'ERROR: Cannot find algorithm "{base}" anywhere. '
+                                         f"Check feature extractor exists!")
+                cp.channel, cp.feature_channel = channel, feature_channel
+                cp.chan_index, cp.chan_weight, cp.chan_names = idx, w, names
+                if not pending:
+                    if cp.external:
+                        plans[(channel, n_samples, nb_pre_plan)] = cp
+                    continue
+                # psd_amp bands ride on a filter slot in the FUSED engine (and only the
+                # lowest bins); otherwise the general ROCFFT engine carries them
+                engine = self._engine
+                bands = [x for x in pending if x[0] == "band"]
+                if bands and engine != "rocfft":
+                    has_of = any(x[0] == "of" for x in pending)
+                    kmax = 0
+                    for x in bands:
+                        rng, _ = utils.cleanup_freq_ranges(x[4]["f_lims"])
+                        kmax = max([kmax] + [hi for _, hi in utils.get_bin_ranges(rng, n_samples,
+                                                                                  self._fs)])
+                    if not has_of or kmax > FUSED_MAX_BAND_BIN:
+                        engine = "rocfft"
+                plan = OFPlan(n_samples, nb_pre_plan, self._fs, max_batch=self._max_batch,
+                              device=self._device, engine=engine)
+                if len(self._channels) > 1 or len(idx) > 1 or w[0] != 1.0:
+                    plan.set_channels(len(self._channels), idx, w)
+                cols = []
+                for kind, algorithm, base, skey, params, wmin, wmax, npre in pending:
+                    if kind == "of":
+                        if skey not in slots:
+                            slot = len(slots)
+                            tag, csd_tag, coupling, peaks, harm, inorm = skey
+                            # filter lookup uses the first physical channel of the expression
+                            fchan = channel if channel in self._filter_data._filter_data else names[0]
+                            template, _, tmeta = self._filter_data.get_template(
+                                fchan, tag=tag, return_metadata=True)
+                            csd, _, cmeta = self._filter_data.get_csd(
+                                fchan, tag=csd_tag, fold=False, return_metadata=True)
+                            if "sample_rate" in cmeta and cmeta["sample_rate"] != self._fs:
+                                raise ValueError(f"Sample rate is not consistent between raw "
+                                                 f"data and csd for channel {channel}!")
+                            if n_samples != csd.shape[-1]:
+                                raise ValueError(
+                                    f"Number of samples is not consistent between raw data "
+                                    f"(={n_samples}) and csd (={csd.shape[-1]})for channel "
+                                    f"{channel}, algorithm {algorithm}!")
+                            if n_samples != template.shape[-1]:
+                                raise ValueError(
+                                    f'Number of samples is not consistent between raw data and '
+                                    f'template ("{tag}") for channel {channel}, algorithm '
+                                    f"{algorithm}!")
+                            pre_t = int(tmeta.get("nb_pretrigger_samples", npre))
+                            if pre_t != nb_pre_plan:
+                                raise ValueError("ERROR: template pretrigger differs from the "
+                                                 "trace pretrigger")
+                            tables = build_filter(template, csd, self._fs, pre_t, coupling,
+                                                  list(peaks) if peaks else None, harm, inorm)
+                            plan.set_filter(slot, tables)
+                            slots[skey] = slot
+                        slot = slots[skey]
+                        skind, qtys = OF_ALGORITHMS[base]
+                        fcut = float(params.get("lowchi2_fcutoff", 10000))
+                        interp = bool(params.get("interpolate", False)) and skind == "delay"
+                        if base == "of1x1_constrained":
+                            lo, hi = search_range(n_samples, nb_pre_plan, self._fs,
+                                                  params.get("window_min_from_trig_usec"),
+                                                  params.get("window_max_from_trig_usec"),
+                                                  wmin, wmax, self._policy)
+                            sid = plan.add_search(slot, "delay", lo, hi,
+                                                  bool(params.get("lgc_outside_window", False)),
+                                                  fcut, interp)
+                        else:
+                            sid = plan.add_search(slot, skind, lowchi2_fcutoff=fcut,
+                                                  interpolate=interp)
+                        cols.append(("of", slot, sid, qtys, algorithm))
+                    elif kind == "band":
+                        rng, rnames = utils.cleanup_freq_ranges(params["f_lims"])
+                        for (klo, khi), rname in zip(utils.get_bin_ranges(rng, n_samples, self._fs),
+                                                     rnames):
+                            cols.append(("band", plan.add_band(klo, khi), f"{algorithm}_{rname}"))
+                    elif kind == "energy":
+                        if wmin < 1:
+                            raise ValueError("ERROR: energyabsorbed needs a window starting after "
+                                             "sample 0 (its baseline is mean(trace[:window_min]))")
+                        for key in ((0, wmin), (wmin, wmax)):
+                            if key not in td_windows:
+                                td_windows[key] = plan.add_tdwindow(*key)
+                        cols.append(("energy", td_windows[(0, wmin)], td_windows[(wmin, wmax)],
+                                     wmax - wmin, params, algorithm))
+                    else:
+                        hi = wmax              # end-exclusive slice trace[wmin:wmax]
+                        key = (wmin, hi)
                         if key not in td_windows:
-                            td_windows[key] = plan.add_tdwindow(*key)
-                    cols.append(("energy", td_windows[(0, wmin)], td_windows[(wmin, wmax)],
-                                 wmax - wmin, params, algorithm))
-                else:
-                    hi = wmax              # end-exclusive slice trace[wmin:wmax]
-                    key = (wmin, hi)
-                    if key not in td_windows:
-                        td_windows[key] = plan.add_tdwindow(wmin, hi)
-                    cols.append(("td", td_windows[key], base, algorithm))
-            for c in cols:
-                if c[0] == "of":
-                    _, slot, sid, qtys, algorithm = c
-                    off = plan.search_offset(slot, sid)
-                    for q in qtys:
-                        cp.columns.append((f"{q}_{algorithm}_{feature_channel}",
-                                           off + _lib.COL[q]))
-                elif c[0] == "band":
-                    cp.columns.append((f"{c[2]}_{feature_channel}", plan.band_offset(c[1])))
-                elif c[0] == "energy":
-                    _, wb, ww, nwin, params, algorithm = c
-                    cp.energy.append((f"{algorithm}_{feature_channel}", plan.tdwindow_offset(wb),
-                                      plan.tdwindow_offset(ww), nwin, float(params["vb"]),
-                                      float(params["i0"]), float(params["rl"])))
-                else:
-                    _, wid, base, algorithm = c
-                    off = plan.tdwindow_offset(wid)
-                    cp.columns.append((f"{algorithm}_{feature_channel}", off + _lib.TD[base]))
-            cp.plan = plan
-            plans[channel] = cp
+                            td_windows[key] = plan.add_tdwindow(wmin, hi)
+                        cols.append(("td", td_windows[key], base, algorithm))
+                for c in cols:
+                    if c[0] == "of":
+                        _, slot, sid, qtys, algorithm = c
+                        off = plan.search_offset(slot, sid)
+                        for q in qtys:
+                            cp.columns.append((f"{q}_{algorithm}_{feature_channel}",
+                                               off + _lib.COL[q]))
+                    elif c[0] == "band":
+                        cp.columns.append((f"{c[2]}_{feature_channel}", plan.band_offset(c[1])))
+                    elif c[0] == "energy":
+                        _, wb, ww, nwin, params, algorithm = c
+                        cp.energy.append((f"{algorithm}_{feature_channel}", plan.tdwindow_offset(wb),
+                                          plan.tdwindow_offset(ww), nwin, float(params["vb"]),
+                                          float(params["i0"]), float(params["rl"])))
+                    else:
+                        _, wid, base, algorithm = c
+                        off = plan.tdwindow_offset(wid)
+                        cp.columns.append((f"{algorithm}_{feature_channel}", off + _lib.TD[base]))
+                cp.plan = plan
+                plans[(channel, n_samples, nb_pre_plan)] = cp
         self._plans = plans
-        self._compiled_n = n_samples
+        self._compiled_n = default_n
+        self._compiled_streams = bool(from_streams)
 
     # ----------------------------------------------------------------- process
     def columns(self):
@@ -317,7 +324,8 @@ class FeatureProcessing:
         if shape[1] != len(self._channels):
             raise ValueError(f"ERROR: traces have {shape[1]} channels, expected "
                              f"{len(self._channels)}")
-        if self._plans is None or self._compiled_n != shape[2]:
+        if (self._plans is None or self._compiled_n != shape[2]
+                or getattr(self, "_compiled_streams", False)):
             self._compile(shape[2])
         def run(cp):
             tr = traces
@@ -331,14 +339,18 @@ class FeatureProcessing:
         processing_data.py:640-656, 674-684).  adc: int16 [C, n_stream] (C =
         len(available_channels)), NumPy or CUDA tensor; trigger_index: int64 [B];
         scale / offset: per channel ADC -> amps (pytesio ``adctoamp``); n_samples: trace
-        length (default: the configured ``nb_samples``).  Windows that do not fit in the
-        stream come back as -999999.0."""
+        length of algorithms that do not carry their own (default: the configured
+        ``nb_samples``); algorithms with their own ``nb_samples`` / ``nb_pretrigger_samples``
+        get their own window around the same trigger, as in the reference
+        (processing_data.py:640-656).  Windows that do not fit in the stream come back as
+        -999999.0."""
         n = int(n_samples or self._nb_samples or 0)
         if n <= 0:
             raise ValueError("ERROR: process_adc needs the trace length (n_samples= or "
                              "nb_samples in the configuration)")
-        if self._plans is None or self._compiled_n != n:
-            self._compile(n)
+        if (self._plans is None or self._compiled_n != n
+                or not getattr(self, "_compiled_streams", False)):
+            self._compile(n, from_streams=True)
         if adc.shape[0] != len(self._channels):
             raise ValueError(f"ERROR: adc has {adc.shape[0]} channels, expected "
                              f"{len(self._channels)}")

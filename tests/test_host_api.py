@@ -419,6 +419,36 @@ def test_feature_processing_from_adc_streams():
     assert list(df.columns) == list(df2.columns)
     assert np.array_equal(df.to_numpy(), df2.to_numpy())
     assert (df.iloc[4] == -999999.0).all() and (df.iloc[5] == -999999.0).all()
+    # an algorithm with its own trace length gets its own window around the same trigger
+    # (config.py:547-572, processing_data.py:640-656)
+    n2, pre2 = 8192, 2048
+    from detprocess_amd import OFPlan, build_filter
+    t2 = synth.make_template(n2, pre2, FS)
+    J2 = synth.make_psd(n2, FS)
+    fd2, _ = _filter_data(n, pre)
+    fd2.set_template("Melange1pc1ch", t2, sample_rate=FS, pretrigger_length_samples=pre2, tag="short")
+    fd2.set_psd("Melange1pc1ch", J2, np.fft.fftfreq(n2, d=1 / FS), sample_rate=FS, tag="short")
+    yaml2 = YAML.replace("    baseline:\n        run: True\n        window_min_from_start_usec: 0",
+                         "    of1x1_short:\n        run: True\n        base_algorithm: of1x1_unconstrained\n"
+                         "        template_tag: short\n        csd_tag: short\n"
+                         f"        nb_samples: {n2}\n        nb_pretrigger_samples: {pre2}\n"
+                         "    baseline:\n        run: True\n        window_min_from_start_usec: 0", 1)
+    fp2 = FeatureProcessing(yaml2, fd2, CHANS, FS, engine="auto", nb_samples=n,
+                            nb_pretrigger_samples=pre)
+    df3 = fp2.process_adc(adc, trig, scale, offset)
+    assert np.array_equal(df3["amp_of1x1_unconstrained_Melange1pc1ch"], df["amp_of1x1_unconstrained_Melange1pc1ch"])
+    lo2 = trig - pre2
+    ok2 = (lo2 >= 0) & (lo2 + n2 <= n_stream)
+    ev2 = np.zeros((len(trig), n2), dtype=np.float32)
+    for b in np.nonzero(ok2)[0]:
+        ev2[b] = adc[0, lo2[b]:lo2[b] + n2].astype(np.float32) * np.float32(scale[0]) + np.float32(offset[0])
+    p2 = OFPlan(n2, pre2, FS, max_batch=16)
+    p2.set_filter(0, build_filter(t2, J2, FS, pre2))
+    sid = p2.add_search(0, "delay")
+    want = p2.process(ev2, valid=ok2.astype(np.uint8))
+    assert np.array_equal(df3["amp_of1x1_short_Melange1pc1ch"].to_numpy(dtype=np.float32), want[:, 0])
+    with pytest.raises(ValueError, match="Number of samples is not consistent"):
+        fp2.process(ev)
 
 
 @pytest.mark.gpu
