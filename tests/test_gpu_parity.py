@@ -398,6 +398,50 @@ def test_full_size_properties():
                  "", ft.ampres, FS, "full-size sample")
 
 
+@pytest.mark.parametrize("n", [25000, 4096])
+def test_lds_engine_properties_at_scale(n):
+    """The LDS engine on a large device-generated batch of the reference example's trace
+    length (and a short power of two): bin-for-bin agreement with the independent ROCFFT
+    engine up to near-tie flips, idempotence, linearity, circular-shift equivariance, a
+    sample against the oracle."""
+    import torch
+    from detprocess_amd import OFPlan, synth_traces
+    pre, B = n // 2, (1 << 31) // (n * 4) // 2
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    ft = build_filter(tmpl, psd, FS, pre)
+    sigma = float(np.sqrt(np.median(psd) * FS))
+    x, truth = synth_traces(B, n, tmpl, sigma, 30 * ft.ampres, 300 * ft.ampres, 0.5, n // 16, seed=4)
+    plans = {}
+    for engine in ("lds", "rocfft"):
+        p = OFPlan(n, pre, FS, max_batch=8192, device=0, engine=engine)
+        p.set_filter(0, ft)
+        p.add_search(0, "delay")
+        p.add_search(0, "delay", pre - n // 64, pre + n // 64)
+        plans[engine] = p
+    a = plans["lds"].process(x)
+    b = plans["rocfft"].process(x)
+    for off in (0, 8):
+        diff = a[:, off + 7] != b[:, off + 7]
+        assert float(diff.float().mean()) < 1e-4
+        assert torch.allclose(a[:, off + 2], b[:, off + 2], rtol=1e-4)
+        assert torch.allclose(a[~diff, off], b[~diff, off], rtol=1e-4, atol=1e-3 * ft.ampres)
+    assert torch.equal(plans["lds"].process(x), a)
+    has = truth[:, 0] > 0
+    dd = (a[has, 7] - pre - truth[has, 1]).abs()
+    assert float((dd <= 2).float().mean()) > 0.999
+    a2 = plans["lds"].process(x[:4096] * 2.0)
+    assert torch.equal(a2[:, 7], a[:4096, 7])
+    assert torch.allclose(a2[:, 0], 2 * a[:4096, 0], rtol=1e-6)
+    a3 = plans["lds"].process(torch.roll(x[:4096], 100, dims=1))
+    assert torch.equal(a3[:, 7], (a[:4096, 7] + 100) % n)
+    idx = np.random.default_rng(1).choice(B, 24, replace=False)
+    sel = torch.as_tensor(idx, device=x.device)
+    ref = orc.process_events(orc.OFFilter(tmpl, psd, FS, pre), x[sel].cpu().numpy().astype(np.float64),
+                             "unconstrained")
+    check_search(a[sel].cpu().numpy().astype(np.float64), 0, ref, "", ft.ampres, FS, f"lds/{n}")
+
+
 def test_coloured_noise_generator_matches_its_psd():
     """ofx_synth_traces_psd draws noise = irfft(sqrt(J N fs / 2) xi): through the
     optimal filter built from the same J, E[chi2_0] = N - 1 (AC coupling) and the
