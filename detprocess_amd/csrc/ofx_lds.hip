@@ -49,7 +49,8 @@ struct __attribute__((aligned(16))) LdsPair {
     float wkx, wky;        // wf_k
     float wpx, wpy;        // wf_p   (p = M - k; k = 0: the Nyquist bin)
     float gk, gp;          // chi2 weights w g of the two bins (0 if the pair is one bin)
-    float pad0, pad1;
+    int k;                 // the bin (pairs are stored in order of pk, not of k: consecutive
+    float pad1;            // lanes then touch consecutive-ish LDS positions)
 };
 
 struct LdsSlot {
@@ -305,9 +306,10 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
             LdsPair cur;
             if (tid <= M / 2) cur = pt[tid];
 #pragma unroll 2
-            for (int k = tid; k <= M / 2; k += BT) {
+            for (int it = tid; it <= M / 2; it += BT) {
                 LdsPair nxt;
-                if (k + BT <= M / 2) nxt = pt[k + BT];
+                if (it + BT <= M / 2) nxt = pt[it + BT];
+                const int k = cur.k;
                 const int p = (k == 0) ? 0 : M - k;
                 const cpx zk = z[cur.pk], zp = z[cur.pp];
                 const float cs = cur.tx, sn = cur.ty;
@@ -602,6 +604,7 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
                     const int kp = (k == 0) ? M : pidx;
                     LdsPair& e = tab[(size_t)si * np + k];
                     memset(&e, 0, sizeof(e));
+                    e.k = k;
                     e.pk = pos_of(k, g);
                     e.pp = pos_of(pidx, g);
                     e.tx = (float)std::cos(c0 * k);
@@ -616,6 +619,8 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
                         e.gp = (kp == k) ? 0.0f : (float)(((kp == M) ? 1.0 : 2.0) * h.g_host[kp]);
                     }
                 }
+                std::sort(tab.begin() + (size_t)si * np, tab.begin() + (size_t)(si + 1) * np,
+                          [](const LdsPair& a, const LdsPair& b) { return a.pk < b.pk; });
                 ++si;
                 if (si >= ntab) break;
             }
