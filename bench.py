@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--traces", type=int, default=1 << 20,
                     help="events resident per GPU (default 1M = BASELINE configs[1])")
-    ap.add_argument("--engine", default="auto", choices=["auto", "fused", "rocfft"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "fused", "rocfft", "lds"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,6 +112,10 @@ def main():
     maxB = int((free - (6 << 30)) // (N_SAMPLES * 4 + 64))
     if B > maxB:
         B = maxB
+    if world > 1:       # every rank must hold the same number of events (weak scaling, all-gather)
+        tb = torch.tensor([B], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.MIN)
+        B = int(tb.item())
     traces = torch.empty((B, N_SAMPLES), dtype=torch.float32, device=dev)
     chunk = 1 << 16
     for b0 in range(0, B, chunk):     # counter-based: (seed, global event index)
