@@ -21,6 +21,16 @@
 // (VT = 2: 256-thread workgroups, 64 complex = 128 VGPRs of data, two workgroups
 // resident per CU so that one computes while the other sits in LDS / barrier / HBM
 // waits, and every thread has two independent instruction streams).
+//
+// Arithmetic is packed fp32 (ofx_fft_regs.h: a complex value = one aligned VGPR pair, one
+// v_pk_* instruction per complex operation).  Stage-1 twiddles come from ten per-thread
+// anchors, the middle-step twiddles from a per-thread base times compile-time constants;
+// only the filter (24 bytes per bin pair) is streamed from L2.  Kernel variants:
+//   FEAT  bit 0 windowed / interpolating searches (lags dumped to LDS), bit 1 time-domain
+//         windows, bit 2 channel algebra on load
+//   MULTI several filter slots share the forward transform (spectrum parked per workgroup)
+// Build-time switches (diagnostics, see tools/README.md): OFX_VT / OFX_WGPC (128-VGPR,
+// four-waves-per-SIMD layout), OFX_MID_DEPTH, ABL_NOEXCH / ABL_NOTAB / ABL_NOTAIL / ABL_LOADONLY.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
