@@ -452,7 +452,7 @@ def test_feature_processing_from_adc_streams():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("engine", ["fused", "rocfft"])
+@pytest.mark.parametrize("engine", ["fused", "rocfft", "lds"])
 def test_psd_amp_and_energyabsorbed(engine):
     """psd_amp (algorithms.py:952-1044) and
     energyabsorbed (:889-949) reuse data the kernel already holds."""
