@@ -573,6 +573,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
+                cpx s2 = mk(0.0f, 0.0f), sq2 = mk(0.0f, 0.0f);            // full rows, packed
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
                     const int r0 = 1024 * n1;
@@ -583,8 +584,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                             // (dependent forms only: anything that is a function of d
                             // alone would be hoisted out of the window loop and spilled)
                             const cpx v = d[32 * h + n1];
-                            s = (s + v.x) + v.y;
-                            sq = fmaf(v.x, v.x, fmaf(v.y, v.y, sq));
+                            s2 = s2 + v;
+                            sq2 = pfma(v, v, sq2);
                             mx = max3f(mx, v.x, v.y);
                             mn = min3f(mn, v.x, v.y);
                         }
@@ -603,8 +604,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         }
                     }
                 }
-                s = ofx_wave_sum(s);
-                sq = ofx_wave_sum(sq);
+                s = ofx_wave_sum(s + (s2.x + s2.y));
+                sq = ofx_wave_sum(sq + (sq2.x + sq2.y));
                 mx = ofx_wave_max(mx);
                 mn = ofx_wave_min(mn);
                 if (lane == 0) {
