@@ -143,6 +143,8 @@ struct ofx_plan {
     void* d_lds_tw = nullptr;            // LDS engine: twiddle table exp(-2 pi i j / N), slot table
     void* d_lds_slots = nullptr;
     void* d_lds_pos = nullptr;           // ... per-slot pair tables (LdsPair)
+    void* d_lds_spec = nullptr;          // ... per-workgroup spectrum scratch (several slots)
+    size_t lds_spec_bytes = 0;
     unsigned long long filter_stamp = 0; // bumped by set_filter / add_search / reset
     unsigned long long lds_pair_stamp = ~0ull;
     int lds_pair_slots = 0;

@@ -11,7 +11,8 @@
 // by addressing bins through pos(k); the inverse is the exact mirror (conjugate twiddle, then
 // inverse radix butterfly, stages in reverse order) and leaves A(2m) + i A(2m+1) in natural
 // order, so the searches scan LDS.  Twiddles come from one table exp(-2 pi i j / N), j < N
-// (L2-resident).  LDS-bound: 2 x (#stages) passes over the trace in LDS per slot.
+// (L2-resident).  LDS-bound: 2 x (#stages) passes over the trace in LDS per slot (the
+// forward half only once when a plan has several slots).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                                             const LdsPair* __restrict__ pairs,
                                             const float* __restrict__ traces,
                                             const uint8_t* __restrict__ valid, long long n_traces,
-                                            float* __restrict__ out) {
+                                            float* __restrict__ out, float2* __restrict__ spec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx* z = reinterpret_cast<cpx*>(smem);                         // [M]
     cpx* vlow = z + g.M;                                           // [LDS_VLOW]
@@ -229,9 +230,18 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
             return acc;
         };
         const int pass_n = (nslots > 0) ? nslots : 1;
+        // several slots: the (digit-reversed) spectrum is parked in this workgroup's scratch
+        // area after the first forward transform and read back for the other slots, so the
+        // load and the forward transform are paid once per event
+        float2* myspec = spec ? spec + (size_t)blockIdx.x * M : nullptr;
         for (int si = 0; si < pass_n; ++si) {
             __syncthreads();                       // previous readers of z are done
-            if (si == 0 && have_pf) {
+            if (si > 0) {
+                for (int m = tid; m < M; m += BT) {
+                    const float2 v = myspec[m];
+                    z[m] = mk(v.x, v.y);
+                }
+            } else if (have_pf) {
                 // the trace was requested during the previous event's searches
 #pragma unroll
                 for (int i = 0; i < NPF; ++i) {
@@ -289,13 +299,17 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                 __syncthreads();
             }
             // -------------------------------------------------------------- forward
-            {
+            if (si == 0) {
                 int L = M;
                 for (int i = 0; i < g.nfac; ++i) {
                     stage_any<true>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
                     L /= g.fac[i];
                     __syncthreads();
                 }
+                if (pass_n > 1)
+                    for (int m = tid; m < M; m += BT) myspec[m] = make_float2(z[m].x, z[m].y);
+            } else {
+                __syncthreads();
             }
             // ------------------------------------------------ middle (k_mid algebra)
             const OfxSlotDev* sdp = (nslots > 0) ? &slots[si].sd : nullptr;
@@ -488,6 +502,9 @@ int ofx_lds_release(ofx_plan* p) {
     if (p->d_lds_tw) (void)hipFree(p->d_lds_tw);
     if (p->d_lds_slots) (void)hipFree(p->d_lds_slots);
     if (p->d_lds_pos) (void)hipFree(p->d_lds_pos);
+    if (p->d_lds_spec) (void)hipFree(p->d_lds_spec);
+    p->d_lds_spec = nullptr;
+    p->lds_spec_bytes = 0;
     p->d_lds_pos = nullptr;
     p->d_lds_tw = nullptr;
     p->d_lds_slots = nullptr;
@@ -509,6 +526,17 @@ static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int n
     if (per_cu > by_threads) per_cu = by_threads;
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)p->cu_count * per_cu;
+    if (nslots > 1) {
+        // per-workgroup spectrum scratch (sized for the full grid, allocated once)
+        const size_t need = (size_t)grid * g.M * sizeof(float2);
+        if (p->lds_spec_bytes < need) {
+            if (p->d_lds_spec) (void)hipFree(p->d_lds_spec);
+            p->d_lds_spec = nullptr;
+            p->lds_spec_bytes = 0;
+            OFX_HIP(hipMalloc(&p->d_lds_spec, need));
+            p->lds_spec_bytes = need;
+        }
+    }
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
@@ -516,7 +544,8 @@ static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int n
     hipLaunchKernelGGL((k_lds<BT, PF>), dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
                        reinterpret_cast<const LdsSlot*>(p->d_lds_slots), nslots,
                        reinterpret_cast<const float2*>(p->d_lds_tw),
-                       reinterpret_cast<const LdsPair*>(p->d_lds_pos), d_traces, d_valid, n, d_out);
+                       reinterpret_cast<const LdsPair*>(p->d_lds_pos), d_traces, d_valid, n, d_out,
+                       nslots > 1 ? reinterpret_cast<float2*>(p->d_lds_spec) : nullptr);
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
