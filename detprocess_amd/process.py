@@ -47,11 +47,15 @@ class _ChannelPlan:
 class FeatureProcessing:
     def __init__(self, config, filter_data, available_channels, sample_rate,
                  nb_samples=None, nb_pretrigger_samples=None, device=0, engine="auto",
-                 max_batch=8192, window_policy="qetpy", external_file=None):
+                 max_batch=8192, window_policy="qetpy", external_file=None,
+                 skip_unsupported=False):
         """config: YamlConfig, YAML path / text, or dict.  available_channels: the
         channel names of axis 1 of the event array, in order.  external_file: a Python
         file exposing ``class FeatureExtractors`` with user algorithms
-        (features.py:248-263, 1002-1029)."""
+        (features.py:248-263, 1002-1029).  skip_unsupported: channels / algorithms outside the
+        of1x1 hot path (multi-channel ``a|b`` entries, ofnxm, of1x2x2, psd_peaks, phase) are
+        skipped with a warning instead of raising, so that a full detprocess YAML such as
+        examples/processing/process_example.yaml can be used as it is."""
         if isinstance(available_channels, str):
             available_channels = [available_channels]
         self._channels = list(available_channels)
@@ -67,6 +71,7 @@ class FeatureProcessing:
         self._nb_samples = nb_samples
         self._nb_pretrigger = nb_pretrigger_samples
         self._plans = None
+        self._skip_unsupported = bool(skip_unsupported)
         self._ext = None
         self._ext_names = []
         if external_file is not None:
@@ -107,6 +112,11 @@ class FeatureProcessing:
                 continue
             feature_channel = algorithms.get("feature_channel", channel)
             if "|" in channel:
+                if self._skip_unsupported:
+                    import warnings
+                    warnings.warn(f'multi-channel OF ("{channel}") is outside the of1x1 hot path '
+                                  f"of this engine: skipped")
+                    continue
                 raise ValueError(f'ERROR: multi-channel OF ("{channel}") is not supported '
                                  f"by this engine (of1x1 family only)")
             names, sep = utils.split_channel_name(channel, self._channels)
@@ -185,6 +195,11 @@ class FeatureProcessing:
                         cp.external.append((algorithm, base, kw, params,
                                             any(p in base for p in OF_BASE_PREFIXES)))
                     elif any(p in base for p in OF_BASE_PREFIXES):
+                        if self._skip_unsupported:
+                            import warnings
+                            warnings.warn(f'algorithm "{base}" is outside the of1x1 hot path of '
+                                          f"this engine: skipped")
+                            continue
                         raise NotImplementedError(
                             f'algorithm "{base}" is outside the of1x1 hot path of this engine')
                     else:

@@ -384,6 +384,97 @@ def test_external_extractor_file(tmp_path):
         FeatureProcessing(yaml_text, fd, CHANS, FS).process(ev)
 
 
+YAML_25000 = """
+filter_file: /path/to/filter_file.hdf5
+global:
+    trace_length_msec: 20
+    pretrigger_length_msec: 10
+Melange1pc1ch:
+    of1x1_nodelay:
+        run: True
+        template_tag: default
+    of1x1_constrained:
+        run: True
+        template_tag: default
+        window_min_from_trig_usec: -400
+        window_max_from_trig_usec: 400
+    baseline:
+        run: True
+        window_min_from_start_usec: 0
+        window_max_from_trig_usec: -2000
+    integral:
+        run: True
+        window_min_from_trig_usec: -10
+        window_max_from_trig_usec: 500
+    psd_amp:
+        run: True
+        f_lims: [[50, 100], [2000, 4000]]
+Melange025pcLeft,Melange025pcRight:
+    of1x1_unconstrained:
+        run: True
+        template_tag: default
+        interpolate: True
+    maximum:
+        run: True
+Melange025pcLeft+Melange025pcRight:
+    feature_channel: MelangeSum
+    weight_Melange025pcLeft: 0.9
+    weight_Melange025pcRight: 1.1
+    of1x1_constrained:
+        run: True
+        template_tag: default
+        window_min_from_trig_usec: -400
+        window_max_from_trig_usec: 400
+Melange025pcLeft|Melange025pcRight:
+    feature_channel: MelangeLR
+    of2x2:
+        run: True
+        base_algorithm: ofnxm
+        template_tag: default
+"""
+
+
+@pytest.mark.gpu
+def test_example_shaped_config_at_25000_samples():
+    """A configuration shaped like the reference's example (20 ms traces at 1.25 MHz = 25000
+    samples, comma-separated channel blocks, a summed channel, psd_amp, an NxM block that is
+    outside this engine): runs on the LDS engine through the YAML driver."""
+    from detprocess_amd import FeatureProcessing
+    from oracle import of1x1 as orc
+    n, pre, B = 25000, 12500, 7
+    fd, J = _filter_data(n, pre)
+    tmpl = synth.make_template(n, pre, FS)
+    filt = orc.OFFilter(tmpl, J, FS, pre)
+    ev, _, _ = synth.make_traces(B * 4, tmpl, J, FS, filt.ampres, seed=5, max_delay=n // 16)
+    ev = ev.reshape(B, 4, n).astype(np.float32)
+    with pytest.raises(ValueError, match="multi-channel OF"):
+        FeatureProcessing(YAML_25000, fd, CHANS, FS).process(ev)
+    with pytest.warns(UserWarning, match="outside the of1x1 hot path"):
+        fp = FeatureProcessing(YAML_25000, fd, CHANS, FS, skip_unsupported=True)
+        df = fp.process(ev)
+    assert {cp.plan.engine for cp in fp._plans.values()} == {"lds"}
+    x0 = ev[:, 0, :].astype(np.float64)
+    rn = orc.process_events(filt, x0, "nodelay")
+    assert np.allclose(df["amp_of1x1_nodelay_Melange1pc1ch"], rn["amp"], rtol=2e-5, atol=1e-4 * filt.ampres)
+    rc = orc.process_events(filt, x0, "constrained", window_min_from_trig_usec=-400,
+                            window_max_from_trig_usec=400)
+    assert np.array_equal(np.round(df["t0_of1x1_constrained_Melange1pc1ch"] * FS), rc["index"] - pre)
+    assert np.allclose(df["chi2_of1x1_constrained_Melange1pc1ch"], rc["chi2"], rtol=2e-5,
+                       atol=2e-6 * rc["chi2nopulse"].max())
+    for j, ch in ((1, "Melange025pcLeft"), (2, "Melange025pcRight")):
+        ri = orc.process_events(filt, ev[:, j, :].astype(np.float64), "unconstrained", interpolate=True)
+        assert np.allclose(df[f"t0_of1x1_unconstrained_{ch}"], ri["t0"], rtol=0, atol=1e-3 / FS)
+        assert np.array_equal(df[f"maximum_{ch}"], ev[:, j, :-1].max(axis=1).astype(np.float64))
+    xs = 0.9 * ev[:, 1, :].astype(np.float64) + 1.1 * ev[:, 2, :].astype(np.float64)
+    rs = orc.process_events(filt, xs, "constrained", window_min_from_trig_usec=-400,
+                            window_max_from_trig_usec=400)
+    assert np.allclose(df["amp_of1x1_constrained_MelangeSum"], rs["amp"], rtol=3e-5, atol=2e-4 * filt.ampres)
+    pa = orc.psd_amp(x0, FS, [[50, 100], [2000, 4000]])
+    for name, v in pa.items():
+        assert np.allclose(df[f"psd_amp_{name}_Melange1pc1ch"], v, rtol=1e-4)
+    assert not any("MelangeLR" in c for c in df.columns)
+
+
 @pytest.mark.gpu
 def test_feature_processing_from_adc_streams():
     """The YAML-driven batch driver on events cut from continuous int16 streams equals the
