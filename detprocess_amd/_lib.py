@@ -53,6 +53,15 @@ _SYMBOLS = [
     ("ofx_trigger_get_traces", C.c_int, [_p, _p, _p, C.c_int, _p]),
     ("ofx_trigger_find", C.c_int, [_p, C.c_double, C.c_longlong, _p, _p, _p, C.c_longlong,
                                    C.POINTER(C.c_longlong), _p]),
+    ("ofx_nxm_create", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                 C.c_int, C.c_int]),
+    ("ofx_nxm_destroy", C.c_int, [_p]),
+    ("ofx_nxm_set_filter", C.c_int, [_p, _p, _p, _p]),
+    ("ofx_nxm_add_search", C.c_int, [_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("ofx_nxm_reset_searches", C.c_int, [_p]),
+    ("ofx_nxm_set_channels", C.c_int, [_p, C.c_int, _p]),
+    ("ofx_nxm_row_floats", C.c_int, [_p]),
+    ("ofx_nxm_process", C.c_int, [_p, _p, _p, C.c_longlong, C.c_int, _p, C.c_int, _p]),
     ("ofx_synth_traces", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                    C.c_ulonglong, _p]),

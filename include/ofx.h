@@ -282,6 +282,46 @@ int ofx_trigger_find(ofx_trigger* trig, double chi2_threshold, long long pileup_
                      long long* index, float* delta_chi2, float* amplitude,
                      long long max_triggers, long long* n_triggers, void* stream);
 
+/* ------------------------------------------------------------------------
+ * N-channel x M-template optimal filter.
+ * Replaces, per batch of events, qp.OFnxm(of_base=, channels='a|b', template_tag=).calc()
+ * + get_fit_withdelay(window..., lgc_outside_window) + get_fit_nodelay() as called by
+ * FeatureExtractors.ofnxm (detprocess/core/algorithms.py:241-262), and the per-channel
+ * update_signal / calc_signal_filt(_td) of processing_data.py:746-772 for those channels.
+ * n_chan, n_tmpl <= 4; n_samples even.  The one-time precompute (template FFTs, inverse
+ * CSD per bin, weight matrix: processing_data.py:294-381) is done by the caller in fp64.
+ * --------------------------------------------------------------------- */
+typedef struct ofx_nxm ofx_nxm;
+
+int ofx_nxm_create(ofx_nxm** out, int n_samples, int n_pretrigger, double fs, int n_chan,
+                   int n_tmpl, int max_batch, int device);
+int ofx_nxm_destroy(ofx_nxm* nxm);
+
+/*
+ * One-sided fp64 tables, K = n_samples/2 + 1 bins, interleaved (re, im):
+ *   phi  [n_tmpl][n_chan][K]  phi_mb(k) = sum_a conj(S_am(k)) Ci_ab(k)   (NumPy FFT of the
+ *                             templates, Ci = inverse two-sided CSD, 0 at dropped bins)
+ *   icov [n_chan][n_chan][K]  Ci_ab(k)
+ *   pinv [n_tmpl][n_tmpl]     inverse of P_mm' = Re sum_k sum_b phi_mb S_bm' / (N fs)
+ */
+int ofx_nxm_set_filter(ofx_nxm* nxm, const double* phi, const double* icov, const double* pinv);
+
+/* kind OFX_SEARCH_NODELAY (n = 0) or OFX_SEARCH_DELAY over rolled bins [lo, hi) (outside != 0:
+ * the complement).  Returns the search id (>= 0) or -OFX_ERR_*.  Output record of search s:
+ * floats [s (n_tmpl + 3) ...]: amplitudes (n_tmpl), t0 (s), chi2, rolled index. */
+int ofx_nxm_add_search(ofx_nxm* nxm, int kind, int lo, int hi, int outside);
+int ofx_nxm_reset_searches(ofx_nxm* nxm);
+
+/* events arrive as [n_events][n_channels_total][n_samples]; channel b of the fit is
+ * index[b] (default: the first n_chan channels of n_chan) */
+int ofx_nxm_set_channels(ofx_nxm* nxm, int n_channels_total, const int* index);
+int ofx_nxm_row_floats(const ofx_nxm* nxm);
+
+/* as ofx_process: host buffers are staged in max_batch chunks, device pointers are
+ * processed in place on the given hipStream_t; events with valid[e] == 0 give sentinel rows */
+int ofx_nxm_process(ofx_nxm* nxm, const float* events, const uint8_t* valid, long long n_events,
+                    int events_mem, float* out, int out_mem, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,235 @@
+"""N-channel x M-template optimal filter (algorithms.py:141-274):
+oracle known-answer tests and host precompute on the CPU, GPU parity through the C ABI."""
+import numpy as np
+import pytest
+
+from detprocess_amd import synth
+from oracle import of1x1 as o1
+from oracle import ofnxm as onm
+
+FS = 1.25e6
+# fp64 -> fp32 tolerances, as for of1x1 (tests/util.py): amplitudes 2e-5 relative plus 1e-4 of
+# their resolution; chi2 2e-5 relative plus 2e-6 of chi2_0; the time bin exact
+AMP_RTOL, AMP_ATOL_SIGMA, CHI_RTOL, CHI_ATOL_CHI0 = 2e-5, 1e-4, 2e-5, 2e-6
+
+
+def make_csd(n, n_chan, rho=0.3):
+    """Hermitian positive-definite two-sided CSD [C, C, n] with complex off-diagonal terms."""
+    J = synth.make_psd(n, FS)
+    sgn = np.sign(np.fft.fftfreq(n, d=1 / FS))
+    scale = np.array([1.0, 1.5, 0.7, 2.0])[:n_chan]
+    csd = np.zeros((n_chan, n_chan, n), dtype=np.complex128)
+    for a in range(n_chan):
+        csd[a, a] = J * scale[a]
+        for b in range(a + 1, n_chan):
+            csd[a, b] = rho * J * np.sqrt(scale[a] * scale[b]) * np.exp(0.4j * (b - a) * sgn)
+            csd[b, a] = np.conj(csd[a, b])
+    return csd
+
+
+def make_templates(n, pre, n_chan, n_tmpl):
+    kinds = ["pulse", "muon", "glitch", "pulse"]
+    share = np.array([[1.0, 0.2, 0.5, 0.1], [0.4, 1.0, -0.3, 0.6], [0.7, -0.5, 1.0, 0.2],
+                      [0.2, 0.3, 0.4, 1.0]])
+    t = np.zeros((n_chan, n_tmpl, n))
+    for m in range(n_tmpl):
+        shape = synth.make_template(n, pre, FS, kinds[m])
+        if m == 3:
+            shape = np.roll(shape, 40)
+        for a in range(n_chan):
+            t[a, m] = share[a, m] * shape
+    return t
+
+
+def make_events(B, templates, csd, ampres, seed, max_delay):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    C, M, n = templates.shape
+    ev = np.zeros((B, C, n))
+    for a in range(C):
+        ev[:, a] = synth.coloured_noise(rng, B, csd[a, a].real, FS)
+    amps = np.where(rng.random((B, M)) < 0.6,
+                    ampres * np.exp(rng.uniform(np.log(3), np.log(300), (B, M))), 0.0)
+    d = rng.integers(-max_delay, max_delay + 1, B)
+    for e in range(B):
+        for m in range(M):
+            ev[e] += amps[e, m] * np.roll(templates[:, m], d[e], axis=-1)
+    return ev, amps, d
+
+
+# ------------------------------------------------------------------ CPU: oracle + host tables
+def test_oracle_reduces_to_of1x1():
+    n, pre = 1024, 400
+    tmpl = synth.make_template(n, pre, FS)
+    J = synth.make_psd(n, FS)
+    f1 = o1.OFFilter(tmpl, J, FS, pre)
+    fn = onm.NxMFilter(tmpl[None, None], J[None, None], FS, pre)
+    assert np.isclose(fn.P[0, 0], f1.norm, rtol=1e-12)
+    x, _, _ = synth.make_traces(6, tmpl, J, FS, f1.ampres, seed=3, max_delay=100)
+    r1 = o1.process_events(f1, x, "constrained", window_min_from_trig_usec=-100,
+                           window_max_from_trig_usec=100)
+    rn = onm.process_events(fn, x[:, None, :], window_min_from_trig_usec=-100,
+                            window_max_from_trig_usec=100)
+    assert np.array_equal(rn["index"], r1["index"])
+    assert np.allclose(rn["amps"][:, 0], r1["amp"], rtol=1e-10)
+    assert np.allclose(rn["chi2"], r1["chi2"], rtol=1e-9)
+    r0 = o1.process_events(f1, x, "nodelay")
+    assert np.allclose(rn["amps_nodelay"][:, 0], r0["amp"], rtol=1e-10)
+    assert np.allclose(rn["chi2_nodelay"], r0["chi2"], rtol=1e-9)
+
+
+def test_oracle_known_answer_noise_free():
+    """A noise-free sum of the templates shifted by d is fitted exactly: amplitudes recovered,
+    t0 = d / fs, chi2 = 0 (up to rounding of chi2_0)."""
+    n, pre, C, M = 2048, 1000, 3, 2
+    t = make_templates(n, pre, C, M)
+    filt = onm.NxMFilter(t, make_csd(n, C), FS, pre)
+    a = np.array([3e-7, -1.2e-7])
+    for d in (0, 17, -40):
+        x = np.einsum("m,amn->an", a, np.roll(t, d, axis=-1))
+        r = onm.fit(filt, x)
+        assert r["index"] == pre + d and np.isclose(r["t0"], d / FS)
+        assert np.allclose(r["amps"], a, rtol=1e-9)
+        assert abs(r["chi2"]) < 1e-9 * r["chi2_0"]
+    # weight matrix: symmetric positive definite, resolutions from its inverse
+    assert np.all(np.linalg.eigvalsh(filt.P) > 0)
+    assert np.allclose(filt.ampres ** 2, np.diag(np.linalg.inv(filt.P)))
+    # the window restricts the search; lgc_outside_window searches the complement
+    x = np.einsum("m,amn->an", a, np.roll(t, 300, axis=-1))
+    r_in = onm.fit(filt, x, window_min_from_trig_usec=-100, window_max_from_trig_usec=100)
+    lo, hi = o1.search_range(filt, -100, 100)
+    assert lo <= r_in["index"] < hi
+    r_out = onm.fit(filt, x, window_min_from_trig_usec=-100, window_max_from_trig_usec=100,
+                    lgc_outside_window=True)
+    assert r_out["index"] == pre + 300
+
+
+def test_host_tables_match_oracle():
+    from detprocess_amd.ofnxm import build_nxm_filter, nxm_search_range
+    n, pre, C, M = 1000, 300, 2, 3
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    filt = onm.NxMFilter(t, csd, FS, pre, ignored_frequency_peaks=[60.0, 5000.0])
+    tab = build_nxm_filter(t, csd, FS, pre, ignored_frequency_peaks=[60.0, 5000.0])
+    k = n // 2 + 1
+    assert tab.phi.shape == (M, C, k) and tab.icov.shape == (C, C, k) and tab.pinv.shape == (M, M)
+    assert np.allclose(tab.phi, np.moveaxis(filt.phi, 0, 2)[:, :, :k], rtol=1e-12, atol=0)
+    assert np.allclose(tab.icov, np.moveaxis(filt.icov, 0, 2)[:, :, :k], rtol=1e-12, atol=0)
+    assert np.allclose(tab.pinv, filt.Pinv, rtol=1e-10)
+    assert np.allclose(tab.ampres, filt.ampres, rtol=1e-10)
+    assert nxm_search_range(n, pre, FS, -100, 100) == o1.search_range(filt, -100, 100)
+    assert nxm_search_range(n, pre, FS, None, None, 10, 50) == o1.search_range(filt, None, None, 10, 50)
+    with pytest.raises(ValueError):
+        build_nxm_filter(t, csd[:, :, :-2], FS, pre)
+    with pytest.raises(ValueError):
+        build_nxm_filter(t[:1], csd, FS, pre)
+
+
+# ------------------------------------------------------------------------------ GPU parity
+def _check(plan, out, sid, ref, filt, nodelay=False):
+    amps, t0, chi2, idx = plan.record(out.astype(np.float64), sid)
+    key = "_nodelay" if nodelay else ""
+    if not nodelay:
+        want = ref["index"].astype(np.int64)
+        got = idx.astype(np.int64)
+        assert np.array_equal(got, want), f"time bins differ at {np.nonzero(got != want)[0]}"
+        assert np.allclose(t0, ref["t0"], rtol=1e-6, atol=1e-12)
+    else:
+        assert np.all(idx == filt.pre) and np.all(t0 == 0)
+    ra = ref["amps" + key]
+    assert np.all(np.abs(amps - ra) <= AMP_RTOL * np.abs(ra) + AMP_ATOL_SIGMA * filt.ampres)
+    rc = ref["chi2" + key]
+    assert np.all(np.abs(chi2 - rc) <= CHI_RTOL * np.abs(rc) + CHI_ATOL_CHI0 * ref["chi2_0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,pre,C,M", [(4096, 2048, 2, 2), (32768, 16384, 2, 2), (25000, 12500, 3, 2),
+                                       (2048, 500, 1, 1), (4096, 2048, 4, 4), (8192, 4096, 2, 3)])
+def test_nxm_gpu_matches_oracle(n, pre, C, M):
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter, nxm_search_range
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    filt = onm.NxMFilter(t, csd, FS, pre)
+    B = 24 if n <= 8192 else 10
+    ev, _, _ = make_events(B, t, csd, filt.ampres, seed=n + C, max_delay=min(n // 8, 2000))
+    plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=16)     # several chunks + a tail
+    lo, hi = nxm_search_range(n, pre, FS, -100, 100)
+    s_nd = plan.add_search("nodelay")
+    s_un = plan.add_search("delay")
+    s_co = plan.add_search("delay", lo, hi)
+    s_out = plan.add_search("delay", lo, hi, outside=True)
+    assert plan.row_floats == 4 * (M + 3)
+    out = plan.process(ev.astype(np.float32))
+    x = ev.astype(np.float32).astype(np.float64)
+    r_un = onm.process_events(filt, x)
+    _check(plan, out, s_nd, r_un, filt, nodelay=True)
+    _check(plan, out, s_un, r_un, filt)
+    _check(plan, out, s_co, onm.process_events(filt, x, window_min_from_trig_usec=-100,
+                                               window_max_from_trig_usec=100), filt)
+    _check(plan, out, s_out, onm.process_events(filt, x, window_min_from_trig_usec=-100,
+                                                window_max_from_trig_usec=100,
+                                                lgc_outside_window=True), filt)
+
+
+@pytest.mark.gpu
+def test_nxm_channel_map_valid_mask_and_device_buffers():
+    import torch
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter
+    n, pre, C, M = 4096, 2048, 2, 2
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    filt = onm.NxMFilter(t, csd, FS, pre)
+    ev, _, _ = make_events(20, t, csd, filt.ampres, seed=9, max_delay=300)
+    full = np.zeros((20, 4, n), dtype=np.float32)
+    full[:, 3] = ev[:, 0]
+    full[:, 1] = ev[:, 1]
+    full[:, 0] = 1e-6                                         # channels the fit must not touch
+    full[:, 2] = -1e-6
+    plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=8)
+    plan.set_channels(4, [3, 1])
+    sid = plan.add_search("delay", pre - 400, pre + 400)
+    valid = np.ones(20, dtype=np.uint8)
+    valid[[2, 11]] = 0
+    out = plan.process(full, valid)
+    ref = onm.process_events(filt, ev.astype(np.float32).astype(np.float64),
+                             window_min_index=pre - 400, window_max_index=pre + 400)
+    ok = valid.astype(bool)
+    assert np.all(out[~ok] == -999999.0)
+    sub = {k: v[ok] for k, v in ref.items()}
+    _check(plan, out[ok], sid, sub, filt)
+    # device-resident events: same numbers, no host staging
+    dev = plan.process(torch.from_numpy(full).cuda(), torch.from_numpy(valid).cuda())
+    assert np.array_equal(dev.cpu().numpy(), out)
+    # empty window -> sentinel record; bad shapes and missing searches raise
+    plan.reset_searches()
+    with pytest.raises(Exception):
+        plan.process(full)
+    s_empty = plan.add_search("delay", 100, 100)
+    o2 = plan.process(full)
+    assert np.all(plan.record(o2, s_empty)[2] == -999999.0)
+    with pytest.raises(ValueError):
+        plan.process(full[:, :2])
+
+
+@pytest.mark.gpu
+def test_nxm_1x1_agrees_with_the_of1x1_engine():
+    """N = M = 1 is the single-template filter: the NxM engine and the of1x1 engines give the
+    same bins and, within fp32 rounding, the same amplitudes and chi2."""
+    from detprocess_amd import OFPlan, build_filter
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter
+    n, pre = 8192, 4096
+    tmpl = synth.make_template(n, pre, FS)
+    J = synth.make_psd(n, FS)
+    ft = build_filter(tmpl, J, FS, pre)
+    x, _, _ = synth.make_traces(32, tmpl, J, FS, ft.ampres, seed=4, max_delay=500)
+    x = x.astype(np.float32)
+    p1 = OFPlan(n, pre, FS, max_batch=64)
+    p1.set_filter(0, ft)
+    s1 = p1.add_search(0, "delay")
+    o1x1 = p1.process(x)
+    pn = NxMPlan(build_nxm_filter(tmpl[None, None], J[None, None], FS, pre), max_batch=64)
+    sn = pn.add_search("delay")
+    amps, t0, chi2, idx = pn.record(pn.process(x[:, None, :]), sn)
+    off = p1.search_offset(0, s1)
+    assert np.array_equal(idx, o1x1[:, off + 7])
+    assert np.allclose(amps[:, 0], o1x1[:, off + 0], rtol=1e-4, atol=1e-3 * ft.ampres)
+    assert np.allclose(chi2, o1x1[:, off + 2], rtol=1e-4)
