@@ -1,7 +1,7 @@
 """FeatureExtractors: the reference's static-method API, computed on the GPU.
 
 Same names, arguments, returned keys, sentinel and error behaviour as
-``detprocess/core/algorithms.py`` (``of1x1_nodelay`` :277-350,
+``detprocess/core/algorithms.py`` (``ofnxm`` :141-274, ``of1x1_nodelay`` :277-350,
 ``of1x1_unconstrained`` :354-432, ``of1x1_constrained`` :435-570, ``baseline``
 :650-704, ``integral`` :708-765, ``maximum`` :770-824, ``minimum`` :829-885).
 Differences: ``of_base`` is ``detprocess_amd.OFBase`` and traces may be batches
@@ -94,6 +94,58 @@ def _td_feature(trace, which, fs, window_min_index, window_max_index):
 
 class FeatureExtractors:
     """Static methods, one per feature algorithm, returning {feature_name: value}."""
+
+    @staticmethod
+    def ofnxm(channel, of_base, available_channels=None, feature_base_name="ofnxm",
+              template_tag=None, amplitude_names=None, window_min_from_trig_usec=None,
+              window_max_from_trig_usec=None, window_min_index=None, window_max_index=None,
+              lgc_outside_window=False, lowchi2_fcutoff=10000, interpolate_t0=False, **kwargs):
+        """NxM optimal filter of an ``a|b`` channel (algorithms.py:141-274): the windowed delay
+        fit (``*_constrained``) and the no-delay fit (``*_nodelay``) of M amplitudes."""
+        if template_tag is None:
+            raise ValueError(f'ERROR: Missing "template_tag" argument for channel {channel}, '
+                             f'algorithm "{feature_base_name}"')
+        template = of_base.template(channel, template_tag=template_tag)
+        if template is None:
+            raise ValueError(f'ERROR: Missing template for channel {channel}, tag '
+                             f'"{template_tag}", algorithm "{feature_base_name}"')
+        if template.ndim != 3:
+            raise ValueError(f"ERROR: the template of channel {channel} must be "
+                             f"[n_channels, n_amplitudes, samples]")
+        ntmps = template.shape[1]
+        if amplitude_names is None:
+            amplitude_names = [f"amp{i + 1}" for i in range(ntmps)]
+        else:
+            if isinstance(amplitude_names, str):
+                amplitude_names = [amplitude_names]
+            if len(amplitude_names) != ntmps:
+                raise ValueError(f'ERROR: Wrong length for "amplitude_names" argument. Expecting '
+                                 f'{ntmps} name for  channel {channel}, algorithm '
+                                 f'"{feature_base_name}"')
+        if interpolate_t0:
+            raise ValueError('ERROR: "interpolate_t0" is not supported by the GPU NxM filter')
+        ret = {f"chi2_{feature_base_name}_constrained": SENTINEL,
+               f"t0_{feature_base_name}_constrained": SENTINEL}
+        for name in amplitude_names:
+            ret[f"{name}_{feature_base_name}_constrained"] = SENTINEL
+        ret[f"chi2_{feature_base_name}_nodelay"] = SENTINEL
+        for name in amplitude_names:
+            ret[f"{name}_{feature_base_name}_nodelay"] = SENTINEL
+        if not of_base.is_signal_stored(channel):
+            return ret
+        lo, hi = search_range(template.shape[-1], of_base.pretrigger_samples(channel, template_tag),
+                              of_base.sample_rate(), window_min_from_trig_usec,
+                              window_max_from_trig_usec, window_min_index, window_max_index)
+        r = of_base.fit_nxm(channel, template_tag, lo, hi, bool(lgc_outside_window))
+        sq = of_base.squeeze(channel)
+        ret[f"chi2_{feature_base_name}_constrained"] = _maybe_scalar(r["chi2"], sq)
+        ret[f"t0_{feature_base_name}_constrained"] = _maybe_scalar(r["t0"], sq)
+        for i, name in enumerate(amplitude_names):
+            ret[f"{name}_{feature_base_name}_constrained"] = _maybe_scalar(r["amps"][:, i], sq)
+        ret[f"chi2_{feature_base_name}_nodelay"] = _maybe_scalar(r["chi2_nodelay"], sq)
+        for i, name in enumerate(amplitude_names):
+            ret[f"{name}_{feature_base_name}_nodelay"] = _maybe_scalar(r["amps_nodelay"][:, i], sq)
+        return ret
 
     @staticmethod
     def of1x1_nodelay(channel, of_base, template_tag=None, lowchi2_fcutoff=10000,

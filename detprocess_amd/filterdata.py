@@ -37,6 +37,15 @@ def fold_spectrum(spectrum, fs):
     return f, out
 
 
+def _channel_name(channels):
+    """'a|b' or ['a', 'b'] -> ('a|b', 2): the multi-channel naming of filterdata.py:414-416."""
+    if isinstance(channels, str):
+        names = [c.strip() for c in channels.split("|")]
+    else:
+        names = [str(c) for c in channels]
+    return "|".join(names), len(names)
+
+
 class FilterData:
     def __init__(self, verbose=True, filter_data=None):
         self._verbose = verbose
@@ -48,10 +57,13 @@ class FilterData:
                      metadata=None, tag="default"):
         if not isinstance(template, np.ndarray):
             raise ValueError('ERROR: "template" argument should be a numpy array!')
-        if not isinstance(channels, str):
-            raise ValueError("ERROR: only single-channel templates are supported here")
-        if template.ndim != 1:
+        channels, nb_channels = _channel_name(channels)
+        if nb_channels == 1 and template.ndim != 1:
             raise ValueError("ERROR: Expecting a 1D array for single channel template")
+        if nb_channels > 1 and (template.ndim != 3 or template.shape[0] != nb_channels):
+            # filterdata.py:560-576: [nb_channels, nb_templates, nb_samples]
+            raise ValueError("ERROR: For multiple channels, expecting 3D array "
+                             "[nb channels, nb templates, nb samples]")
         metadata = dict(metadata) if metadata else {}
         if sample_rate is None and "sample_rate" in metadata:
             sample_rate = float(metadata["sample_rate"])
@@ -101,12 +113,36 @@ class FilterData:
         ch[f"psd_{tag}_inds"] = psd_freqs.copy()
         ch[f"psd_{tag}_metadata"] = metadata
 
-    def set_csd(self, channels, csd, csd_freqs, **kwargs):
-        """Single-channel CSD == PSD (get_csd falls back to get_psd, filterdata.py:417-420)."""
+    def set_csd(self, channels, csd, csd_freqs, sample_rate=None, metadata=None, tag="default",
+                **kwargs):
+        """Single-channel CSD == PSD (get_csd falls back to get_psd, filterdata.py:417-420);
+        an ``a|b`` channel stores the two-sided [nb_channels, nb_channels, nb_samples] array."""
         csd = np.asarray(csd)
-        if csd.ndim == 3 and csd.shape[0] == 1 and csd.shape[1] == 1:
-            csd = csd[0, 0]
-        self.set_psd(channels, np.real(csd), csd_freqs, **kwargs)
+        channels, nb_channels = _channel_name(channels)
+        if nb_channels == 1:
+            if csd.ndim == 3 and csd.shape[0] == 1 and csd.shape[1] == 1:
+                csd = csd[0, 0]
+            self.set_psd(channels, np.real(csd), csd_freqs, sample_rate=sample_rate,
+                         metadata=metadata, tag=tag, **kwargs)
+            return
+        csd_freqs = np.asarray(csd_freqs, dtype=np.float64)
+        if csd.ndim != 3 or csd.shape[0] != nb_channels or csd.shape[1] != nb_channels \
+                or csd_freqs.shape != csd.shape[-1:]:
+            raise ValueError("ERROR: csd shape is not consistent with number of channels")
+        if not np.any(csd_freqs < 0):
+            raise ValueError("ERROR: csd needs to be two-sided!")
+        metadata = dict(metadata) if metadata else {}
+        fs_arr = _estimate_sampling_rate(csd_freqs)
+        if sample_rate is None:
+            sample_rate = float(metadata.get("sample_rate", fs_arr))
+        elif round(fs_arr) != round(sample_rate):
+            raise ValueError("ERROR: sample_rate is inconsistent with frequency array!")
+        metadata.update(sample_rate=float(sample_rate), nb_samples=int(csd.shape[-1]),
+                        channel=channels)
+        ch = self._filter_data.setdefault(channels, dict())
+        ch[f"csd_{tag}"] = np.array(csd, dtype=np.complex128)
+        ch[f"csd_{tag}_inds"] = csd_freqs.copy()
+        ch[f"csd_{tag}_metadata"] = metadata
 
     # ---------------------------------------------------------------- getters
     def _get_param_array(self, param_name, channel, tag="default", return_metadata=False):
@@ -134,7 +170,18 @@ class FilterData:
         return (psd, freqs, meta) if return_metadata else (psd, freqs)
 
     def get_csd(self, channels, tag="default", fold=False, return_metadata=False):
-        return self.get_psd(channels, tag=tag, fold=fold, return_metadata=return_metadata)
+        channels, nb_channels = _channel_name(channels)
+        if nb_channels == 1:
+            return self.get_psd(channels, tag=tag, fold=fold, return_metadata=return_metadata)
+        csd, freqs, meta = self._get_param_array("csd", channels, tag, True)   # filterdata.py:422-428
+        if fold:
+            fs = float(meta.get("sample_rate", _estimate_sampling_rate(freqs)))
+            n = csd.shape[-1]
+            k = n // 2 + 1
+            freqs = np.fft.rfftfreq(n, d=1.0 / fs)
+            csd = csd[..., :k].copy()
+            csd[..., 1:(k if n % 2 else k - 1)] *= 2.0
+        return (csd, freqs, meta) if return_metadata else (csd, freqs)
 
     def describe(self):
         for chan, d in self._filter_data.items():

@@ -16,6 +16,12 @@ import numpy as np
 from . import _lib
 from .engine import OFPlan
 from .filters import apply_coupling_and_notches, build_filter
+from .ofnxm import NxMPlan, build_nxm_filter
+
+
+def _split(channel):
+    """'a|b|c' -> ['a', 'b', 'c'] (the NxM channel naming, utils.split_channel_name with '|')."""
+    return [c.strip() for c in channel.split("|")]
 
 
 def search_range(nb_samples, nb_pretrigger_samples, fs,
@@ -66,6 +72,9 @@ class OFBase:
         self._signals = {}        # channel -> traces [B, N] float32 (numpy or cuda tensor)
         self._squeeze = {}        # channel -> bool (input was a single 1-D trace)
         self._plans = {}          # (N, pre) -> OFPlan
+        self._csd_nxm = {}        # 'a|b' -> dict(csd [C, C, N], coupling, peaks, harmonics)
+        self._nxm_tables = {}     # ('a|b', tag) -> NxMTables
+        self._nxm_plans = {}      # ('a|b', tag) -> NxMPlan
         self._fit_cache = {}
 
     # ------------------------------------------------------------ description
@@ -89,9 +98,23 @@ class OFBase:
     def set_csd(self, channel, csd, coupling="AC", ignored_frequency_peaks=None,
                 ignore_harmonics=False):
         csd = np.asarray(csd)
+        if csd.ndim == 3 and csd.shape[0] > 1:
+            # 'a|b' channel: the N x N cross spectral density (processing_data.py:294-326)
+            nchan = len(_split(channel))
+            if csd.shape[0] != nchan or csd.shape[1] != nchan:
+                raise ValueError(f"ERROR: csd of shape {csd.shape} for the {nchan} channel(s) "
+                                 f"of {channel}")
+            self._check_nbins(csd.shape[-1], "csd")
+            self._csd_nxm[channel] = dict(csd=np.array(csd, dtype=np.complex128),
+                                          coupling=coupling, peaks=ignored_frequency_peaks,
+                                          harmonics=ignore_harmonics)
+            for key in [k for k in self._nxm_tables if k[0] == channel]:
+                self._nxm_tables.pop(key)
+                self._drop_nxm_plan(key)
+            return
         if csd.ndim == 3:
-            if csd.shape[0] != 1 or csd.shape[1] != 1:
-                raise ValueError("ERROR: only 1x1 (single channel) csd supported")
+            if csd.shape[1] != 1:
+                raise ValueError("ERROR: csd must be [n_channels, n_channels, samples]")
             csd = csd[0, 0]
         csd = np.real(csd).astype(np.float64)
         self._check_nbins(csd.shape[-1], "csd")
@@ -104,6 +127,8 @@ class OFBase:
         self.set_csd(channel, psd, coupling=coupling, **kw)
 
     def csd(self, channel):
+        if channel in self._csd_nxm:
+            return self._csd_nxm[channel]["csd"]
         return self._csd.get(channel)
 
     psd = csd
@@ -113,10 +138,19 @@ class OFBase:
                      pretrigger_samples=None, pretrigger_msec=None, integralnorm=False,
                      overwrite=False):
         template = np.asarray(template, dtype=np.float64)
-        if template.ndim == 3 and template.shape[0] == 1 and template.shape[1] == 1:
+        if template.ndim == 3 and template.shape[0] == 1 and template.shape[1] == 1 \
+                and "|" not in channel:
             template = template[0, 0]
-        if template.ndim != 1:
-            raise ValueError("ERROR: only single-channel 1-D templates supported")
+        if template.ndim == 3:
+            # NxM: [n_channels, m_amplitudes, samples] (oftrigger.py:375-379)
+            if template.shape[0] != len(_split(channel)):
+                raise ValueError(f"ERROR: template of shape {template.shape} for the "
+                                 f"{len(_split(channel))} channel(s) of {channel}")
+            if integralnorm:
+                raise ValueError("ERROR: integralnorm is not supported for NxM templates")
+        elif template.ndim != 1:
+            raise ValueError("ERROR: template must be [samples] or "
+                             "[n_channels, m_amplitudes, samples]")
         self._check_nbins(template.shape[-1], "template")
         tags = self._templates.setdefault(channel, {})
         if template_tag in tags and not overwrite:
@@ -130,6 +164,13 @@ class OFBase:
         tags[template_tag] = dict(template=template, pre=int(pretrigger_samples),
                                   integralnorm=bool(integralnorm))
         self._tables.pop((channel, template_tag), None)
+        if self._nxm_tables.pop((channel, template_tag), None) is not None:
+            self._drop_nxm_plan((channel, template_tag))
+
+    def _drop_nxm_plan(self, key):
+        plan = self._nxm_plans.pop(key, None)
+        if plan is not None:
+            plan.close()
 
     def template_tags(self, channel):
         return list(self._templates.get(channel, {}).keys())
@@ -144,11 +185,21 @@ class OFBase:
     def calc_phi(self, channel, template_tag=None):
         tags = [template_tag] if template_tag is not None else self.template_tags(channel)
         for tag in tags:
-            if channel not in self._csd:
+            if channel not in self._csd and channel not in self._csd_nxm:
                 raise ValueError(f"ERROR: No csd found for channel {channel}")
             t = self._templates.get(channel, {}).get(tag)
             if t is None:
                 raise ValueError(f'ERROR: No template with tag "{tag}" for channel {channel}')
+            if t["template"].ndim == 3:
+                c = self._csd_nxm.get(channel)
+                if c is None:
+                    raise ValueError(f"ERROR: No {len(_split(channel))}-channel csd found for "
+                                     f"channel {channel}")
+                self._nxm_tables[(channel, tag)] = build_nxm_filter(
+                    t["template"], c["csd"], self._fs, t["pre"], coupling=c["coupling"],
+                    ignored_frequency_peaks=c["peaks"], ignore_harmonics=c["harmonics"])
+                self._drop_nxm_plan((channel, tag))
+                continue
             J = self._csd[channel]
             # J already carries coupling / notches (inf) -> pass coupling="DC" so
             # build_filter does not touch bin 0 again
@@ -164,8 +215,20 @@ class OFBase:
     def phi(self, channel, template_tag="default"):
         """conj(S)/J on the one-sided grid (QETpy's phi up to its FFT normalisation);
         None until calc_phi has run (processing_data.py:379-381)."""
+        if (channel, template_tag) in self._nxm_tables:
+            return self._nxm_tables[(channel, template_tag)].phi
         t = self._tables.get((channel, template_tag))
         return None if t is None else t.wf * t.norm
+
+    def iweight(self, channel, template_tag="default"):
+        """Inverse of the M x M weight matrix of an NxM channel; its diagonal holds the squared
+        amplitude resolutions (oftrigger.py:481, :499)."""
+        return self.nxm_tables(channel, template_tag).pinv
+
+    def nxm_tables(self, channel, template_tag="default"):
+        if (channel, template_tag) not in self._nxm_tables:
+            self.calc_phi(channel, template_tag)
+        return self._nxm_tables[(channel, template_tag)]
 
     def norm(self, channel, template_tag="default"):
         return self.tables(channel, template_tag).norm
@@ -196,6 +259,8 @@ class OFBase:
             self._fit_cache.pop(key)
 
     def is_signal_stored(self, channel):
+        if "|" in channel and channel not in self._signals:
+            return all(c in self._signals for c in _split(channel))
         return channel in self._signals
 
     def calc_signal_filt(self, channel, template_tag=None):
@@ -237,6 +302,42 @@ class OFBase:
         self._fit_cache[ck] = res
         return res
 
+    def fit_nxm(self, channel, template_tag, lo=0, hi=None, outside=False):
+        """qp.OFnxm(...).calc() + get_fit_withdelay + get_fit_nodelay (algorithms.py:241-262) on
+        the stored batch of an 'a|b' channel.  Returns dict: amps [B, M], t0, chi2,
+        amps_nodelay [B, M], chi2_nodelay."""
+        if not self.is_signal_stored(channel):
+            raise ValueError(f"ERROR: no signal stored for channel {channel}")
+        ck = (channel, template_tag, "nxm", lo, hi, bool(outside))
+        if ck in self._fit_cache:
+            return self._fit_cache[ck]
+        tab = self.nxm_tables(channel, template_tag)
+        key = (channel, template_tag)
+        plan = self._nxm_plans.get(key)
+        if plan is None:
+            plan = self._nxm_plans[key] = NxMPlan(tab, max_batch=min(self._max_batch, 2048),
+                                                  device=self._device)
+        if channel in self._signals:                      # stored as one [B, C, N] block
+            ev = self._signals[channel]
+        else:
+            sigs = [self._signals[c] for c in _split(channel)]
+            if isinstance(sigs[0], np.ndarray):
+                ev = np.stack(sigs, axis=1)
+            else:
+                import torch
+                ev = torch.stack(sigs, dim=1)
+        plan.reset_searches()
+        s_nd = plan.add_search("nodelay")
+        s_d = plan.add_search("delay", lo, hi, outside)
+        out = plan.process(ev)
+        if not isinstance(out, np.ndarray):
+            out = out.cpu().numpy()
+        a0, _, c0, _ = plan.record(out, s_nd)
+        a1, t1, c1, _ = plan.record(out, s_d)
+        res = dict(amps=a1, t0=t1, chi2=c1, amps_nodelay=a0, chi2_nodelay=c0)
+        self._fit_cache[ck] = res
+        return res
+
     def psd_bands(self, channel, freq_ranges):
         """psd_amp: mean sqrt(folded PSD) of the stored batch per frequency range
         (algorithms.py:1001-1044); returns a list of float32 arrays [B]."""
@@ -258,4 +359,6 @@ class OFBase:
         return [out[:, plan.band_offset(i)] for i in ids]
 
     def squeeze(self, channel):
+        if "|" in channel and channel not in self._squeeze:
+            return all(self._squeeze.get(c, False) for c in _split(channel))
         return self._squeeze.get(channel, False)

@@ -53,7 +53,7 @@ class FeatureProcessing:
         channel names of axis 1 of the event array, in order.  external_file: a Python
         file exposing ``class FeatureExtractors`` with user algorithms
         (features.py:248-263, 1002-1029).  skip_unsupported: channels / algorithms outside the
-        of1x1 hot path (multi-channel ``a|b`` entries, ofnxm, of1x2x2, psd_peaks, phase) are
+        hot path (of1x2x2, ofnxmx2, psd_peaks, phase; ``ofnxm`` on raw streams) are
         skipped with a warning instead of raising, so that a full detprocess YAML such as
         examples/processing/process_example.yaml can be used as it is."""
         if isinstance(available_channels, str):
@@ -112,13 +112,9 @@ class FeatureProcessing:
                 continue
             feature_channel = algorithms.get("feature_channel", channel)
             if "|" in channel:
-                if self._skip_unsupported:
-                    import warnings
-                    warnings.warn(f'multi-channel OF ("{channel}") is outside the of1x1 hot path '
-                                  f"of this engine: skipped")
-                    continue
-                raise ValueError(f'ERROR: multi-channel OF ("{channel}") is not supported '
-                                 f"by this engine (of1x1 family only)")
+                self._compile_nxm(channel, algorithms, feature_channel, default_n, from_streams,
+                                  plans)
+                continue
             names, sep = utils.split_channel_name(channel, self._channels)
             idx = [self._channels.index(c) for c in names]
             w = np.ones(len(names))
@@ -321,6 +317,114 @@ class FeatureProcessing:
         self._compiled_n = default_n
         self._compiled_streams = bool(from_streams)
 
+    def _unsupported(self, what):
+        if self._skip_unsupported:
+            import warnings
+            warnings.warn(f"{what} is outside the hot path of this engine: skipped")
+            return
+        raise NotImplementedError(f"{what} is outside the hot path of this engine")
+
+    def _compile_nxm(self, channel, algorithms, feature_channel, default_n, from_streams, plans):
+        """An ``a|b`` channel (features.py:692-716 passes the name through; the extractor splits
+        it, algorithms.py:188-192): every running ``ofnxm`` algorithm becomes a delay search of
+        an NxM plan; algorithms with the same trace length, template and csd tags share the
+        plan, its transforms and its no-delay fit."""
+        from .ofnxm import NxMPlan, build_nxm_filter
+        names = [c.strip() for c in channel.split("|")]
+        for c in names:
+            if c not in self._channels:
+                raise ValueError(f'ERROR: Channel "{c}" of "{channel}" is not available! '
+                                 f"Available channels: {self._channels}")
+        idx = [self._channels.index(c) for c in names]
+        groups = {}
+        for algorithm, params in algorithms.items():
+            if not isinstance(params, dict) or not params.get("run", False):
+                continue
+            base = params.get("base_algorithm", algorithm)
+            if base != "ofnxm":
+                self._unsupported(f'algorithm "{base}" of the multi-channel entry "{channel}"')
+                continue
+            if from_streams:
+                self._unsupported(f'"{channel}": the NxM filter on events cut from raw streams')
+                continue
+            nb = params.get("nb_samples") or self._nb_samples or default_n
+            npre = params.get("nb_pretrigger_samples")
+            if npre is None:
+                npre = self._nb_pretrigger if self._nb_pretrigger is not None else nb // 2
+            if nb != default_n:
+                raise ValueError(f"ERROR: Number of samples is not consistent between raw data "
+                                 f"(={default_n}) and algorithm {algorithm} (={nb}) for channel "
+                                 f"{channel}!")
+            if "template_tag" not in params:
+                raise ValueError(f'ERROR: a "template_tag" in yaml file is required for channel '
+                                 f'{channel}, algorithm "{algorithm}" !')
+            if params.get("interpolate_t0", False):
+                raise ValueError('ERROR: "interpolate_t0" is not supported by the GPU NxM filter')
+            peaks = params.get("ignored_frequency_peaks")
+            if peaks is not None and not isinstance(peaks, list):
+                peaks = [peaks]
+            harm = bool(params.get("ignore_harmonics", False)) if peaks else False
+            skey = (int(nb), int(npre), params["template_tag"], params.get("csd_tag", "default"),
+                    params.get("coupling", "AC"), tuple(peaks) if peaks else None, harm)
+            groups.setdefault(skey, []).append((algorithm, params))
+        for skey, algos in groups.items():
+            nb, npre, tag, csd_tag, coupling, peaks, harm = skey
+            template, _, tmeta = self._filter_data.get_template(channel, tag=tag,
+                                                                return_metadata=True)
+            csd, _, cmeta = self._filter_data.get_csd(channel, tag=csd_tag, fold=False,
+                                                      return_metadata=True)
+            if "sample_rate" in cmeta and cmeta["sample_rate"] != self._fs:
+                raise ValueError(f"Sample rate is not consistent between raw data and csd for "
+                                 f"channel {channel}!")
+            if nb != csd.shape[-1]:
+                raise ValueError(f"Number of samples is not consistent between raw data (={nb}) "
+                                 f"and csd (={csd.shape[-1]})for channel {channel}!")
+            if nb != template.shape[-1]:
+                raise ValueError(f'Number of samples is not consistent between raw data and '
+                                 f'template ("{tag}") for channel {channel}!')
+            pre_t = int(tmeta.get("nb_pretrigger_samples", npre))
+            if pre_t != npre:
+                raise ValueError("ERROR: template pretrigger differs from the trace pretrigger")
+            tables = build_nxm_filter(template, csd, self._fs, pre_t, coupling,
+                                      list(peaks) if peaks else None, harm)
+            plan = NxMPlan(tables, max_batch=min(self._max_batch, 2048), device=self._device)
+            plan.set_channels(len(self._channels), idx)
+            cp = _ChannelPlan()
+            cp.nxm = True
+            cp.channel, cp.feature_channel = channel, feature_channel
+            cp.chan_index, cp.chan_names = idx, names
+            m = tables.n_tmpl
+            s_nd = plan.add_search("nodelay")
+            for algorithm, params in algos:
+                amp_names = params.get("amplitude_names")
+                if amp_names is None:
+                    amp_names = [f"amp{i + 1}" for i in range(m)]
+                elif isinstance(amp_names, str):
+                    amp_names = [amp_names]
+                if len(amp_names) != m:
+                    raise ValueError(f'ERROR: Wrong length for "amplitude_names" argument. '
+                                     f"Expecting {m} name for  channel {channel}, algorithm "
+                                     f'"{algorithm}"')                 # algorithms.py:221-226
+                kwargs = {k: v for k, v in params.items() if k != "run"}
+                kwargs["fs"] = self._fs
+                kwargs["nb_samples"], kwargs["nb_pretrigger_samples"] = nb, npre
+                wmin, wmax = utils.get_window_indices(**kwargs)
+                lo, hi = search_range(nb, npre, self._fs, params.get("window_min_from_trig_usec"),
+                                      params.get("window_max_from_trig_usec"), wmin, wmax,
+                                      self._policy)
+                s_d = plan.add_search("delay", lo, hi,
+                                      bool(params.get("lgc_outside_window", False)))
+                od, on = s_d * (m + 3), s_nd * (m + 3)
+                cp.columns.append((f"chi2_{algorithm}_constrained_{feature_channel}", od + m + 1))
+                cp.columns.append((f"t0_{algorithm}_constrained_{feature_channel}", od + m))
+                for i, an in enumerate(amp_names):
+                    cp.columns.append((f"{an}_{algorithm}_constrained_{feature_channel}", od + i))
+                cp.columns.append((f"chi2_{algorithm}_nodelay_{feature_channel}", on + m + 1))
+                for i, an in enumerate(amp_names):
+                    cp.columns.append((f"{an}_{algorithm}_nodelay_{feature_channel}", on + i))
+            cp.plan = plan
+            plans[(channel,) + skey] = cp
+
     # ----------------------------------------------------------------- process
     def columns(self):
         return [name for cp in (self._plans or {}).values()
@@ -344,6 +448,8 @@ class FeatureProcessing:
             self._compile(shape[2])
         def run(cp):
             tr = traces
+            if getattr(cp, "nxm", False):
+                return cp.plan.process(tr, valid=valid)
             if len(self._channels) == 1 and cp.plan.n_channels == 1:
                 tr = traces.reshape(shape[0], shape[2])
             return cp.plan.process(tr, valid=valid)
@@ -373,6 +479,8 @@ class FeatureProcessing:
         of = np.broadcast_to(np.asarray(offset, dtype=np.float64), (len(self._channels),))
 
         def run(cp):
+            if getattr(cp, "nxm", False):
+                raise NotImplementedError("the NxM filter runs on float events only")
             if cp.plan.n_channels == 1 and len(self._channels) == 1:
                 return cp.plan.process_adc(adc, trigger_index, sc[:1], of[:1])
             return cp.plan.process_adc(adc, trigger_index, sc, of)

@@ -430,29 +430,58 @@ Melange025pcLeft|Melange025pcRight:
     of2x2:
         run: True
         base_algorithm: ofnxm
-        template_tag: default
+        amplitude_names: [ampshared, ampslow]
+        window_min_from_trig_usec: -100
+        window_max_from_trig_usec: 100
+        csd_tag: default
+        template_tag: pair
+    of1x2x2_test:
+        run: True
+        base_algorithm: of1x2x2
+        template_tag: pair
 """
 
 
 @pytest.mark.gpu
 def test_example_shaped_config_at_25000_samples():
     """A configuration shaped like the reference's example (20 ms traces at 1.25 MHz = 25000
-    samples, comma-separated channel blocks, a summed channel, psd_amp, an NxM block that is
-    outside this engine): runs on the LDS engine through the YAML driver."""
+    samples, comma-separated channel blocks, a summed channel, psd_amp, a 2x2 ``a|b`` block
+    and an algorithm outside this engine): of1x1 runs on the LDS engine, ofnxm on the NxM
+    engine, through the YAML driver."""
     from detprocess_amd import FeatureProcessing
     from oracle import of1x1 as orc
+    from oracle import ofnxm as onm
+    from test_ofnxm import make_csd, make_templates
     n, pre, B = 25000, 12500, 7
     fd, J = _filter_data(n, pre)
+    pair = "Melange025pcLeft|Melange025pcRight"
+    t2 = make_templates(n, pre, 2, 2)
+    c2 = make_csd(n, 2)
+    fd.set_template(pair, t2, sample_rate=FS, pretrigger_length_samples=pre, tag="pair")
+    fd.set_csd(pair, c2, np.fft.fftfreq(n, d=1 / FS), sample_rate=FS, tag="default")
     tmpl = synth.make_template(n, pre, FS)
     filt = orc.OFFilter(tmpl, J, FS, pre)
     ev, _, _ = synth.make_traces(B * 4, tmpl, J, FS, filt.ampres, seed=5, max_delay=n // 16)
     ev = ev.reshape(B, 4, n).astype(np.float32)
-    with pytest.raises(ValueError, match="multi-channel OF"):
+    with pytest.raises(NotImplementedError, match="of1x2x2"):
         FeatureProcessing(YAML_25000, fd, CHANS, FS).process(ev)
-    with pytest.warns(UserWarning, match="outside the of1x1 hot path"):
+    with pytest.warns(UserWarning, match="outside the hot path"):
         fp = FeatureProcessing(YAML_25000, fd, CHANS, FS, skip_unsupported=True)
         df = fp.process(ev)
-    assert {cp.plan.engine for cp in fp._plans.values()} == {"lds"}
+    assert {cp.plan.engine for cp in fp._plans.values() if not getattr(cp, "nxm", False)} == {"lds"}
+    # the 2x2 block: windowed delay fit + no-delay fit, named as algorithms.py:229-273
+    fn = onm.NxMFilter(t2, c2, FS, pre)
+    rn = onm.process_events(fn, ev[:, 1:3, :].astype(np.float64), window_min_from_trig_usec=-100,
+                            window_max_from_trig_usec=100)
+    assert np.array_equal(np.round(df["t0_of2x2_constrained_MelangeLR"] * FS), rn["index"] - pre)
+    for i, an in enumerate(("ampshared", "ampslow")):
+        for kind, key in (("constrained", "amps"), ("nodelay", "amps_nodelay")):
+            assert np.allclose(df[f"{an}_of2x2_{kind}_MelangeLR"], rn[key][:, i], rtol=2e-5,
+                               atol=1e-4 * fn.ampres[i])
+    for kind, key in (("constrained", "chi2"), ("nodelay", "chi2_nodelay")):
+        assert np.allclose(df[f"chi2_of2x2_{kind}_MelangeLR"], rn[key], rtol=2e-5,
+                           atol=2e-6 * rn["chi2_0"].max())
+    assert not any("of1x2x2" in c for c in df.columns)
     x0 = ev[:, 0, :].astype(np.float64)
     rn = orc.process_events(filt, x0, "nodelay")
     assert np.allclose(df["amp_of1x1_nodelay_Melange1pc1ch"], rn["amp"], rtol=2e-5, atol=1e-4 * filt.ampres)
@@ -472,7 +501,6 @@ def test_example_shaped_config_at_25000_samples():
     pa = orc.psd_amp(x0, FS, [[50, 100], [2000, 4000]])
     for name, v in pa.items():
         assert np.allclose(df[f"psd_amp_{name}_Melange1pc1ch"], v, rtol=1e-4)
-    assert not any("MelangeLR" in c for c in df.columns)
 
 
 @pytest.mark.gpu

@@ -233,3 +233,60 @@ def test_nxm_1x1_agrees_with_the_of1x1_engine():
     assert np.array_equal(idx, o1x1[:, off + 7])
     assert np.allclose(amps[:, 0], o1x1[:, off + 0], rtol=1e-4, atol=1e-3 * ft.ampres)
     assert np.allclose(chi2, o1x1[:, off + 2], rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_feature_extractors_ofnxm_static_method():
+    """FeatureExtractors.ofnxm on an OFBase holding the per-channel signals, as
+    ProcessingData drives it (processing_data.py:294-381, 746-772; algorithms.py:141-274)."""
+    from detprocess_amd import FeatureExtractors as FE, OFBase
+    n, pre, C, M = 4096, 2048, 2, 2
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    filt = onm.NxMFilter(t, csd, FS, pre)
+    ev, _, _ = make_events(6, t, csd, filt.ampres, seed=2, max_delay=100)
+    ev32 = ev.astype(np.float32)
+    ob = OFBase(FS)
+    ob.set_csd("a|b", csd, coupling="AC")
+    ob.add_template("a|b", t, template_tag="pair", pretrigger_samples=pre)
+    ob.calc_phi("a|b", "pair")
+    assert ob.phi("a|b", "pair").shape == (M, C, n // 2 + 1)
+    assert np.allclose(np.sqrt(np.diag(ob.iweight("a|b", "pair"))), filt.ampres, rtol=1e-10)
+    keys = ["chi2_ofnxm_constrained", "t0_ofnxm_constrained", "amp1_ofnxm_constrained",
+            "amp2_ofnxm_constrained", "chi2_ofnxm_nodelay", "amp1_ofnxm_nodelay",
+            "amp2_ofnxm_nodelay"]
+    r = FE.ofnxm("a|b", ob, template_tag="pair")                     # no signal -> sentinels
+    assert list(r) == keys and all(v == -999999.0 for v in r.values())
+    with pytest.raises(ValueError):
+        FE.ofnxm("a|b", ob)                                          # template tag required
+    with pytest.raises(ValueError):
+        FE.ofnxm("a|b", ob, template_tag="nope")
+    with pytest.raises(ValueError):
+        FE.ofnxm("a|b", ob, template_tag="pair", amplitude_names=["one"])
+    ob.update_signal("a", ev32[:, 0], calc_fft=True)
+    assert not ob.is_signal_stored("a|b")
+    ob.update_signal("b", ev32[:, 1], calc_fft=True)
+    assert ob.is_signal_stored("a|b")
+    r = FE.ofnxm("a|b", ob, template_tag="pair", amplitude_names=["x", "y"],
+                 window_min_from_trig_usec=-50, window_max_from_trig_usec=50,
+                 feature_base_name="of2x2")
+    ref = onm.process_events(filt, ev32.astype(np.float64), window_min_from_trig_usec=-50,
+                             window_max_from_trig_usec=50)
+    assert np.allclose(r["t0_of2x2_constrained"], ref["t0"], rtol=1e-6, atol=1e-12)
+    for i, nm in enumerate(("x", "y")):
+        assert np.allclose(r[f"{nm}_of2x2_constrained"], ref["amps"][:, i], rtol=AMP_RTOL,
+                           atol=AMP_ATOL_SIGMA * filt.ampres[i])
+        assert np.allclose(r[f"{nm}_of2x2_nodelay"], ref["amps_nodelay"][:, i], rtol=AMP_RTOL,
+                           atol=AMP_ATOL_SIGMA * filt.ampres[i])
+    assert np.allclose(r["chi2_of2x2_constrained"], ref["chi2"], rtol=CHI_RTOL,
+                       atol=CHI_ATOL_CHI0 * ref["chi2_0"].max())
+    assert np.allclose(r["chi2_of2x2_nodelay"], ref["chi2_nodelay"], rtol=CHI_RTOL,
+                       atol=CHI_ATOL_CHI0 * ref["chi2_0"].max())
+    # a single event comes back as scalars, as in the reference
+    ob.clear_signal()
+    ob.update_signal("a", ev32[0, 0])
+    ob.update_signal("b", ev32[0, 1])
+    r1 = FE.ofnxm("a|b", ob, template_tag="pair")
+    assert isinstance(r1["amp1_ofnxm_constrained"], float)
+    assert np.isclose(r1["amp1_ofnxm_nodelay"], ref["amps_nodelay"][0, 0], rtol=AMP_RTOL,
+                      atol=AMP_ATOL_SIGMA * filt.ampres[0])
