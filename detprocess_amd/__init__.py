@@ -8,5 +8,6 @@ from .filterdata import FilterData                # noqa: F401
 from .ofbase import OFBase, search_range          # noqa: F401
 from .process import FeatureProcessing            # noqa: F401
 from .oftrigger import OptimumFilterTrigger       # noqa: F401
+from .ofnxm import NxMPlan, build_nxm_filter      # noqa: F401
 
 __version__ = "0.1.0"
