@@ -147,7 +147,55 @@ class YamlConfig:
             cfg[field]["channels"] = expanded
 
         cfg["feature"] = self._configure_features(cfg["feature"], cfg["global"])
+        cfg["trigger"] = self._configure_triggers(cfg["trigger"], cfg["global"])
+        cfg["salting"] = self._configure_salting(cfg["salting"], cfg["global"])
         self._processing_config = cfg
+
+    def _merge_global(self, section, global_config, label):
+        """Shared head of the trigger / salting passes (config.py:285-320, 329-365): global
+        parameters fill the section's ``overall``; every channel needs a dict; returns the copy
+        and the list of physical channels its entries name."""
+        d = copy.deepcopy(section)
+        for k, v in (global_config or {}).items():
+            d["overall"].setdefault(k, v)
+        split_all = []
+        for chan, cc in d["channels"].items():
+            if not isinstance(cc, dict):
+                raise ValueError(f"ERROR: Channel {chan} has no configuration! Remove "
+                                 f"from yaml file or disable it!")
+            names, _ = utils.split_channel_name(chan, self._available_channels)
+            split_all.extend(names)
+        return d, utils.unique_list(split_all)
+
+    def _configure_salting(self, salting_config, global_config):
+        d, d["channel_list"] = self._merge_global(salting_config, global_config, "salting")
+        return d
+
+    def _configure_triggers(self, trigger_config, global_config):
+        """config.py:324-407: an entry either is one trigger (it carries ``run``) or holds one
+        dict per trigger algorithm, stored as ``<algorithm>_<trigger_channel>``;
+        ``trigger_channel`` (formerly ``trigger_name``) renames the channel."""
+        d, channel_list = self._merge_global(trigger_config, global_config, "trigger")
+        out = {}
+        for chan, cc in d["channels"].items():
+            cc = copy.deepcopy(cc)
+            trigger_channel = cc.pop("trigger_channel", chan)
+            if "run" in cc:
+                if not cc["run"]:
+                    continue
+                cc["channel_name"] = chan
+                out[trigger_channel] = cc
+                continue
+            for algo, ac in cc.items():
+                if not isinstance(ac, dict) or "run" not in ac:
+                    raise ValueError(f'ERROR: Missing "run" parameter for trigger channel {chan}')
+                if not ac["run"]:
+                    continue
+                ac["channel_name"] = chan
+                out[f"{algo}_{trigger_channel}"] = ac
+        d["channels"] = out
+        d["channel_list"] = channel_list
+        return d
 
     def _length(self, d, kind, current):
         """kind = 'trace' | 'pretrigger' ; samples win over msec (config.py:457-510)."""
