@@ -62,6 +62,8 @@ _SYMBOLS = [
     ("ofx_nxm_set_channels", C.c_int, [_p, C.c_int, _p]),
     ("ofx_nxm_row_floats", C.c_int, [_p]),
     ("ofx_nxm_process", C.c_int, [_p, _p, _p, C.c_longlong, C.c_int, _p, C.c_int, _p]),
+    ("ofx_nxm_process_adc", C.c_int, [_p, _p, C.c_longlong, C.c_int, _p, C.c_longlong, _p, _p, _p,
+                                      C.c_int, _p]),
     ("ofx_synth_traces", C.c_int, [_p, _p, C.c_longlong, C.c_longlong, C.c_int, _p,
                                    C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                    C.c_ulonglong, _p]),

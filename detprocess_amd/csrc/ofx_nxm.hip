@@ -59,6 +59,10 @@ struct ofx_nxm {
     uint8_t* d_stage_valid = nullptr;
     float* d_stage_out = nullptr;
     size_t stage_out_floats = 0;
+    int16_t* d_adc = nullptr;          // ofx_nxm_process_adc: staged streams, trigger indices
+    size_t adc_elems = 0;
+    long long* d_trig = nullptr;
+    size_t trig_elems = 0;
 };
 
 namespace {
@@ -360,7 +364,8 @@ extern "C" int ofx_nxm_destroy(ofx_nxm* p) {
         if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
     }
     void* bufs[] = {p->d_phi, p->d_icov, p->d_x, p->d_spec, p->d_q, p->d_qt, p->d_chi0p,
-                    p->d_work, p->d_stage_in, p->d_stage_valid, p->d_stage_out};
+                    p->d_work, p->d_stage_in, p->d_stage_valid, p->d_stage_out, p->d_adc,
+                    p->d_trig};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete p;
@@ -495,6 +500,81 @@ extern "C" int ofx_nxm_process(ofx_nxm* p, const float* traces, const uint8_t* v
                                    hipMemcpyDeviceToHost, st));
         if (traces_mem == OFX_MEM_HOST || out_mem == OFX_MEM_HOST)
             OFX_HIP(hipStreamSynchronize(st));
+    }
+    return OFX_OK;
+}
+
+extern "C" int ofx_nxm_process_adc(ofx_nxm* p, const int16_t* adc, long long n_stream, int adc_mem,
+                                   const long long* trigger_index, long long n,
+                                   const double* scale, const double* offset, float* out,
+                                   int out_mem, void* stream) {
+    if (!p || n < 0 || n_stream < 0 || (n > 0 && (!adc || !trigger_index || !out)) || !scale ||
+        !offset) {
+        ofx_set_error("ofx_nxm_process_adc: bad argument");
+        return OFX_ERR_ARG;
+    }
+    if (!p->filter_set || p->searches.empty()) {
+        ofx_set_error("ofx_nxm_process_adc: no filter or no search set");
+        return OFX_ERR_STATE;
+    }
+    if (n == 0) return OFX_OK;
+    OFX_HIP(hipSetDevice(p->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int CT = p->n_total;
+    const size_t ev_floats = (size_t)CT * p->N;
+    const int row = ofx_nxm_row_floats(p);
+    const int16_t* d_adc = adc;
+    if (adc_mem == OFX_MEM_HOST) {
+        const size_t want = (size_t)CT * (size_t)n_stream;
+        if (p->adc_elems < want) {
+            OFX_HIP(hipStreamSynchronize(st));
+            if (p->d_adc) (void)hipFree(p->d_adc);
+            p->d_adc = nullptr;
+            p->adc_elems = 0;
+            OFX_HIP(hipMalloc(&p->d_adc, want * sizeof(int16_t)));
+            p->adc_elems = want;
+        }
+        OFX_HIP(hipMemcpyAsync(p->d_adc, adc, want * sizeof(int16_t), hipMemcpyHostToDevice, st));
+        d_adc = p->d_adc;
+    }
+    if (p->trig_elems < (size_t)n) {
+        OFX_HIP(hipStreamSynchronize(st));
+        if (p->d_trig) (void)hipFree(p->d_trig);
+        p->d_trig = nullptr;
+        p->trig_elems = 0;
+        OFX_HIP(hipMalloc(&p->d_trig, (size_t)n * sizeof(long long)));
+        p->trig_elems = (size_t)n;
+    }
+    OFX_HIP(hipMemcpyAsync(p->d_trig, trigger_index, (size_t)n * sizeof(long long),
+                           hipMemcpyHostToDevice, st));
+    std::vector<float> sc(CT), of(CT);
+    for (int c = 0; c < CT; ++c) {
+        sc[c] = (float)scale[c];
+        of[c] = (float)offset[c];
+    }
+    const long long chunk = p->max_batch;
+    int rc;
+    if ((rc = grow_to(&p->d_stage_in, (size_t)chunk * ev_floats))) return rc;
+    if ((rc = grow_to(&p->d_stage_valid, (size_t)chunk))) return rc;
+    if (out_mem == OFX_MEM_HOST && p->stage_out_floats < (size_t)chunk * row) {
+        OFX_HIP(hipStreamSynchronize(st));
+        if (p->d_stage_out) (void)hipFree(p->d_stage_out);
+        p->d_stage_out = nullptr;
+        p->stage_out_floats = 0;
+        OFX_HIP(hipMalloc(&p->d_stage_out, (size_t)chunk * row * sizeof(float)));
+        p->stage_out_floats = (size_t)chunk * row;
+    }
+    for (long long b0 = 0; b0 < n; b0 += chunk) {
+        const long long nb = (n - b0 < chunk) ? (n - b0) : chunk;
+        rc = ofx_cut_launch(d_adc, n_stream, CT, p->N, p->pre, p->d_trig + b0, nb, sc.data(),
+                            of.data(), p->d_stage_in, p->d_stage_valid, st);
+        if (rc) return rc;
+        float* d_out = (out_mem == OFX_MEM_HOST) ? p->d_stage_out : out + (size_t)b0 * row;
+        if ((rc = process_device(p, p->d_stage_in, p->d_stage_valid, nb, d_out, st))) return rc;
+        if (out_mem == OFX_MEM_HOST)
+            OFX_HIP(hipMemcpyAsync(out + (size_t)b0 * row, d_out, (size_t)nb * row * sizeof(float),
+                                   hipMemcpyDeviceToHost, st));
+        OFX_HIP(hipStreamSynchronize(st));      // the staging buffers are reused by the next chunk
     }
     return OFX_OK;
 }

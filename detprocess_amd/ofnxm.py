@@ -182,6 +182,41 @@ class NxMPlan:
                    "ofx_nxm_process")
         return out
 
+    def process_adc(self, adc, trigger_index, scale, offset):
+        """Events cut on the GPU out of continuous int16 streams ``adc [n_channels_total,
+        n_stream]`` (NumPy or CUDA tensor) around ``trigger_index [B]``, then fitted; scale /
+        offset per channel as in ``OFPlan.process_adc``.  Returns float32 [B, row_floats] of
+        the same kind as ``adc``."""
+        trig = np.ascontiguousarray(trigger_index, dtype=np.int64)
+        b = int(trig.shape[0])
+        ct = self.n_channels_total
+        sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float64), (ct,)))
+        of = np.ascontiguousarray(np.broadcast_to(np.asarray(offset, dtype=np.float64), (ct,)))
+        row = self.row_floats
+        if isinstance(adc, np.ndarray):
+            a = np.ascontiguousarray(adc, dtype=np.int16)
+            if a.ndim != 2 or a.shape[0] != ct:
+                raise ValueError(f"ERROR: adc must be [{ct}, n_stream], got {a.shape}")
+            out = np.empty((b, row), dtype=np.float32)
+            _lib.check(self._lib.ofx_nxm_process_adc(
+                self._h, a.ctypes.data, int(a.shape[1]), _lib.MEM_HOST, trig.ctypes.data, b,
+                sc.ctypes.data, of.ctypes.data, out.ctypes.data, _lib.MEM_HOST, None),
+                "ofx_nxm_process_adc")
+            return out
+        import torch
+        if not (isinstance(adc, torch.Tensor) and adc.is_cuda and adc.dtype == torch.int16):
+            raise TypeError("adc must be an int16 NumPy array or CUDA tensor")
+        a = adc.contiguous()
+        if a.dim() != 2 or a.shape[0] != ct:
+            raise ValueError(f"ERROR: adc must be [{ct}, n_stream], got {tuple(a.shape)}")
+        out = torch.empty((b, row), dtype=torch.float32, device=a.device)
+        stream = torch.cuda.current_stream(a.device).cuda_stream
+        _lib.check(self._lib.ofx_nxm_process_adc(
+            self._h, a.data_ptr(), int(a.shape[1]), _lib.MEM_DEVICE, trig.ctypes.data, b,
+            sc.ctypes.data, of.ctypes.data, out.data_ptr(), _lib.MEM_DEVICE, C.c_void_p(stream)),
+            "ofx_nxm_process_adc")
+        return out
+
     def close(self):
         if self._h:
             self._lib.ofx_nxm_destroy(self._h)

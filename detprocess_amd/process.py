@@ -53,7 +53,7 @@ class FeatureProcessing:
         channel names of axis 1 of the event array, in order.  external_file: a Python
         file exposing ``class FeatureExtractors`` with user algorithms
         (features.py:248-263, 1002-1029).  skip_unsupported: channels / algorithms outside the
-        hot path (of1x2x2, ofnxmx2, psd_peaks, phase; ``ofnxm`` on raw streams) are
+        hot path (of1x2x2, ofnxmx2, psd_peaks, phase) are
         skipped with a warning instead of raising, so that a full detprocess YAML such as
         examples/processing/process_example.yaml can be used as it is."""
         if isinstance(available_channels, str):
@@ -344,14 +344,11 @@ class FeatureProcessing:
             if base != "ofnxm":
                 self._unsupported(f'algorithm "{base}" of the multi-channel entry "{channel}"')
                 continue
-            if from_streams:
-                self._unsupported(f'"{channel}": the NxM filter on events cut from raw streams')
-                continue
             nb = params.get("nb_samples") or self._nb_samples or default_n
             npre = params.get("nb_pretrigger_samples")
             if npre is None:
                 npre = self._nb_pretrigger if self._nb_pretrigger is not None else nb // 2
-            if nb != default_n:
+            if not from_streams and nb != default_n:
                 raise ValueError(f"ERROR: Number of samples is not consistent between raw data "
                                  f"(={default_n}) and algorithm {algorithm} (={nb}) for channel "
                                  f"{channel}!")
@@ -480,7 +477,7 @@ class FeatureProcessing:
 
         def run(cp):
             if getattr(cp, "nxm", False):
-                raise NotImplementedError("the NxM filter runs on float events only")
+                return cp.plan.process_adc(adc, trigger_index, sc, of)
             if cp.plan.n_channels == 1 and len(self._channels) == 1:
                 return cp.plan.process_adc(adc, trigger_index, sc[:1], of[:1])
             return cp.plan.process_adc(adc, trigger_index, sc, of)

@@ -322,6 +322,15 @@ int ofx_nxm_row_floats(const ofx_nxm* nxm);
 int ofx_nxm_process(ofx_nxm* nxm, const float* events, const uint8_t* valid, long long n_events,
                     int events_mem, float* out, int out_mem, void* stream);
 
+/* as ofx_process_adc: the events are cut on the GPU out of continuous int16 streams
+ * adc[n_channels_total][n_stream] around trigger_index[e] (window [t - n_pretrigger,
+ * t - n_pretrigger + n_samples), amps = float32(adc * scale[c]) + offset[c]; a window that does
+ * not fit gives a sentinel row: processing_data.py:640-656, 674-684), then fitted as above.
+ * trigger_index, scale, offset and (for OFX_MEM_HOST) out are host arrays. */
+int ofx_nxm_process_adc(ofx_nxm* nxm, const int16_t* adc, long long n_stream, int adc_mem,
+                        const long long* trigger_index, long long n_events, const double* scale,
+                        const double* offset, float* out, int out_mem, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

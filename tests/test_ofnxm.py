@@ -290,3 +290,73 @@ def test_feature_extractors_ofnxm_static_method():
     assert isinstance(r1["amp1_ofnxm_constrained"], float)
     assert np.isclose(r1["amp1_ofnxm_nodelay"], ref["amps_nodelay"][0, 0], rtol=AMP_RTOL,
                       atol=AMP_ATOL_SIGMA * filt.ampres[0])
+
+
+@pytest.mark.gpu
+def test_nxm_on_events_cut_from_adc_streams():
+    """NxM fit on events cut on the GPU out of int16 streams = the same fit on host-cut,
+    host-converted events, bit for bit (plan level and through the YAML driver)."""
+    import torch
+    from detprocess_amd import FeatureProcessing, FilterData
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter
+    n, pre, C, M = 4096, 1024, 2, 2
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    filt = onm.NxMFilter(t, csd, FS, pre)
+    ev, _, _ = make_events(8, t, csd, filt.ampres, seed=5, max_delay=200)
+    chans = ["x", "a", "b"]                                      # the pair sits in rows 1 and 2
+    n_stream = 8 * n
+    scale = np.array([1.0e-12, 2.0e-12, 2.5e-12])
+    offset = np.array([0.0, -1e-9, 3e-10])
+    adc = np.zeros((3, n_stream), dtype=np.int16)
+    for c in range(2):
+        train = ev[:, c].reshape(-1)
+        adc[c + 1] = np.clip(np.round((train - offset[c + 1]) / scale[c + 1]), -32768, 32767)
+    trig = np.array([pre, n + pre + 7, 3 * n + pre - 40, 7 * n + pre, 7 * n + pre + 1, 10],
+                    dtype=np.int64)
+    lo = trig - pre
+    ok = (lo >= 0) & (lo + n <= n_stream)
+    assert list(ok) == [True, True, True, True, False, False]
+    cut = np.zeros((len(trig), 3, n), dtype=np.float32)
+    for b in np.nonzero(ok)[0]:
+        for c in range(3):
+            cut[b, c] = (adc[c, lo[b]:lo[b] + n].astype(np.float32) * np.float32(scale[c])
+                         + np.float32(offset[c]))
+    plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=4)
+    plan.set_channels(3, [1, 2])
+    plan.add_search("nodelay")
+    plan.add_search("delay", pre - 300, pre + 300)
+    want = plan.process(cut, ok.astype(np.uint8))
+    got = plan.process_adc(adc, trig, scale, offset)
+    assert np.array_equal(got, want)
+    assert np.all(got[~ok] == -999999.0)
+    got_dev = plan.process_adc(torch.from_numpy(adc).cuda(), trig, scale, offset)
+    assert np.array_equal(got_dev.cpu().numpy(), want)
+    # YAML driver: an a|b block next to a single-channel block, both from the same streams
+    fd = FilterData()
+    f = np.fft.fftfreq(n, d=1 / FS)
+    fd.set_template("a|b", t, sample_rate=FS, pretrigger_length_samples=pre, tag="pair")
+    fd.set_csd("a|b", csd, f, sample_rate=FS, tag="default")
+    fd.set_template("a", t[0, 0] / np.max(np.abs(t[0, 0])), sample_rate=FS,
+                    pretrigger_length_samples=pre, tag="default")
+    fd.set_psd("a", csd[0, 0].real, f, sample_rate=FS, tag="default")
+    yaml_text = """
+a:
+    of1x1_nodelay:
+        run: True
+        template_tag: default
+a|b:
+    feature_channel: ab
+    of2x2:
+        run: True
+        base_algorithm: ofnxm
+        template_tag: pair
+        window_min_from_trig_usec: -200
+        window_max_from_trig_usec: 200
+"""
+    fp = FeatureProcessing(yaml_text, fd, chans, FS, nb_samples=n, nb_pretrigger_samples=pre)
+    df = fp.process_adc(adc, trig, scale, offset)
+    df2 = fp.process(cut, valid=ok.astype(np.uint8))
+    assert list(df.columns) == list(df2.columns) and "amp1_of2x2_constrained_ab" in df.columns
+    assert np.array_equal(df.to_numpy(), df2.to_numpy())
+    assert (df.iloc[4] == -999999.0).all()
