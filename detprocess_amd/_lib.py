@@ -47,7 +47,11 @@ _SYMBOLS = [
                                   C.c_int, _p]),
     ("ofx_trigger_create", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_double, _p, C.c_double,
                                      C.c_double, C.c_int]),
+    ("ofx_trigger_create_nxm", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_double, C.c_int,
+                                         C.c_int, _p, _p, _p, C.c_int]),
     ("ofx_trigger_destroy", C.c_int, [_p]),
+    ("ofx_trigger_update_traces", C.c_int, [_p, _p, C.c_int, C.c_longlong, C.c_int, _p, _p,
+                                            C.c_int, _p]),
     ("ofx_trigger_update_trace", C.c_int, [_p, _p, C.c_int, C.c_longlong, C.c_int, C.c_double,
                                            C.c_double, C.c_int, _p]),
     ("ofx_trigger_get_traces", C.c_int, [_p, _p, _p, C.c_int, _p]),

@@ -17,11 +17,17 @@
 
 #include "ofx_common.h"
 
+#define TRIG_MAX 4
+
 struct ofx_trigger {
     int N = 0, pre = 0, device = 0;
+    int C = 1, M = 1;                     // channels x amplitudes (1 x 1: the fused fast path)
     double fs = 0, vscale = 1, w = 1;
+    double iw[TRIG_MAX * TRIG_MAX] = {0}, wm[TRIG_MAX * TRIG_MAX] = {0};   // N x M matrices
     int P = 0, H = 0;                     // FFT block length, hop
-    float2* d_hfft = nullptr;             // [P/2+1] FFT of the zero-padded filter / P
+    float2* d_hfft = nullptr;             // [C][M][P/2+1] FFT of the zero-padded filters / P
+    float2* d_acc = nullptr;  size_t acc_elems = 0;      // N x M: accumulated spectrum of one amplitude
+    float* d_vtd = nullptr;   size_t vtd_elems = 0;      // N x M: [M][n] summed convolutions
     // per-stream state
     long long n = 0, nblk = 0;
     float* d_xpad = nullptr;  size_t xpad_elems = 0;
@@ -102,6 +108,68 @@ __global__ void k_dchi2(const float* __restrict__ yblk, long long n, int N, int 
     dchi[t] = d;
 }
 
+struct TrigMat {
+    float iw[TRIG_MAX * TRIG_MAX];
+    float w[TRIG_MAX * TRIG_MAX];
+};
+
+// N x M: spectrum of amplitude m = sum over channels of spec_b x h[b][m]  (oftrigger.py:656-662:
+// the per-channel convolutions are summed)
+__global__ void k_mulacc(const float2* __restrict__ spec, const float2* __restrict__ h, int C,
+                         int M, int m, int K, long long per_chan, float2* __restrict__ acc) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= per_chan) return;
+    const int k = (int)(i % K);
+    float2 r = make_float2(0.0f, 0.0f);
+    for (int b = 0; b < C; ++b) {
+        const float2 a = spec[(size_t)b * per_chan + i], f = h[((size_t)b * M + m) * K + k];
+        r.x += a.x * f.x - a.y * f.y;
+        r.y += a.x * f.y + a.y * f.x;
+    }
+    acc[i] = r;
+}
+
+// valid part of the overlap-save blocks of one amplitude -> V_td[m][t] ('same' alignment as k_dchi2)
+__global__ void k_extract(const float* __restrict__ yblk, long long n, int N, int P, int H,
+                          float* __restrict__ vtd) {
+    const long long t = (long long)blockIdx.x * TB + threadIdx.x;
+    if (t >= n) return;
+    const long long nf = t + (N - 1) / 2;
+    const long long blk = nf / H;
+    vtd[t] = yblk[blk * P + (int)(nf - blk * H) + (N - 1)];
+}
+
+// filtered = iw V_td ; delta chi2 = filtered^T w filtered ; edges as in k_dchi2 (oftrigger.py:663-679)
+__global__ void k_combine(const float* __restrict__ vtd, long long n, int N, int M, TrigMat mat,
+                          int padding, float* __restrict__ filt, float* __restrict__ dchi) {
+    const long long t = (long long)blockIdx.x * TB + threadIdx.x;
+    if (t >= n) return;
+    float v[TRIG_MAX], a[TRIG_MAX];
+#pragma unroll
+    for (int j = 0; j < TRIG_MAX; ++j) v[j] = j < M ? vtd[(size_t)j * n + t] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TRIG_MAX; ++i) {
+        float r = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TRIG_MAX; ++j) r += mat.iw[i * TRIG_MAX + j] * v[j];
+        a[i] = r;
+        if (i < M) filt[(size_t)i * n + t] = r;
+    }
+    float d = 0.0f;
+#pragma unroll
+    for (int i = 0; i < TRIG_MAX; ++i) {
+        float r = 0.0f;
+#pragma unroll
+        for (int j = 0; j < TRIG_MAX; ++j) r += mat.w[i * TRIG_MAX + j] * a[j];
+        d += a[i] * r;
+    }
+    if (padding) {
+        const long long tail = (long long)N - ((N + 1) % 2);
+        if (t < N || t >= n - tail) d = 0.0f;
+    }
+    dchi[t] = d;
+}
+
 __global__ void k_above(const float* __restrict__ dchi, long long n, float thr,
                         int* __restrict__ last) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
@@ -139,7 +207,7 @@ __global__ void k_best(const float* __restrict__ dchi, const int* __restrict__ r
 
 __global__ void k_emit(const float* __restrict__ dchi, const float* __restrict__ filt,
                        const int* __restrict__ prev, const unsigned long long* __restrict__ key,
-                       long long n, float thr, long long window, long long cap,
+                       long long n, float thr, long long window, long long cap, int M,
                        long long* __restrict__ count, long long* __restrict__ oidx,
                        float* __restrict__ odchi, float* __restrict__ oamp) {
     const long long i = (long long)blockIdx.x * TB + threadIdx.x;
@@ -153,7 +221,7 @@ __global__ void k_emit(const float* __restrict__ dchi, const float* __restrict__
     if (slot < cap) {
         oidx[slot] = best;
         odchi[slot] = dchi[best];
-        oamp[slot] = filt[best];
+        for (int m = 0; m < M; ++m) oamp[slot * M + m] = filt[(size_t)m * n + best];
     }
 }
 
@@ -201,31 +269,13 @@ int make_plans(ofx_trigger* t, long long nblk, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int ofx_trigger_create(ofx_trigger** out, int n_samples, int n_pretrigger, double fs,
-                                  const double* phi_td, double vscale, double w, int device) {
-    if (!out || n_samples < 2 || n_pretrigger < 0 || n_pretrigger >= n_samples || !(fs > 0) ||
-        !phi_td || !(vscale != 0.0) || !(w > 0)) {
-        ofx_set_error("ofx_trigger_create: bad argument");
-        return OFX_ERR_ARG;
-    }
-    OFX_HIP(hipSetDevice(device));
-    ofx_trigger* t = new ofx_trigger();
-    t->N = n_samples;
-    t->pre = n_pretrigger;
-    t->fs = fs;
-    t->vscale = vscale;
-    t->w = w;
-    t->device = device;
-    int P = 1;
-    while (P < 4 * n_samples) P <<= 1;                 // >= 75 % of every block is new output
-    if (P < 4096) P = 4096;
-    t->P = P;
-    t->H = P - (n_samples - 1);
-    // FFT of the zero-padded filter in fp64 on the host (naive O(N P) would be too slow:
-    // use a straightforward radix-2 recursion on the padded array)
+namespace {
+
+// FFT of one zero-padded filter in fp64 on the host (iterative radix-2, P a power of two),
+// scaled by 1/P (rocFFT's inverse is unnormalised); K = P/2 + 1 bins into h
+void padded_filter_fft(const double* phi_td, int n_samples, int P, float2* h) {
     std::vector<double> re(P, 0.0), im(P, 0.0);
     for (int i = 0; i < n_samples; ++i) re[i] = phi_td[i];
-    // iterative radix-2 FFT (P is a power of two)
     for (int i = 1, j = 0; i < P; ++i) {
         int bit = P >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -245,16 +295,77 @@ extern "C" int ofx_trigger_create(ofx_trigger** out, int n_samples, int n_pretri
             }
     }
     const int K = P / 2 + 1;
-    std::vector<float2> h(K);
     for (int k = 0; k < K; ++k) h[k] = make_float2((float)(re[k] / P), (float)(im[k] / P));
-    if (hipMalloc(&t->d_hfft, sizeof(float2) * K) != hipSuccess ||
-        hipMemcpy(t->d_hfft, h.data(), sizeof(float2) * K, hipMemcpyHostToDevice) != hipSuccess ||
+}
+
+int create_common(ofx_trigger** out, int n_samples, int n_pretrigger, double fs, int C, int M,
+                  const double* phi_td, int device) {
+    OFX_HIP(hipSetDevice(device));
+    ofx_trigger* t = new ofx_trigger();
+    t->N = n_samples;
+    t->pre = n_pretrigger;
+    t->fs = fs;
+    t->C = C;
+    t->M = M;
+    t->device = device;
+    int P = 1;
+    while (P < 4 * n_samples) P <<= 1;                 // >= 75 % of every block is new output
+    if (P < 4096) P = 4096;
+    t->P = P;
+    t->H = P - (n_samples - 1);
+    const int K = P / 2 + 1;
+    std::vector<float2> h((size_t)C * M * K);
+    for (int r = 0; r < C * M; ++r)
+        padded_filter_fft(phi_td + (size_t)r * n_samples, n_samples, P, h.data() + (size_t)r * K);
+    if (hipMalloc(&t->d_hfft, sizeof(float2) * h.size()) != hipSuccess ||
+        hipMemcpy(t->d_hfft, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice) !=
+            hipSuccess ||
         hipMalloc(&t->d_count, sizeof(long long)) != hipSuccess) {
         ofx_set_error("ofx_trigger_create: device allocation failed");
         delete t;
         return OFX_ERR_HIP;
     }
     *out = t;
+    return OFX_OK;
+}
+
+}  // namespace
+
+extern "C" int ofx_trigger_create(ofx_trigger** out, int n_samples, int n_pretrigger, double fs,
+                                  const double* phi_td, double vscale, double w, int device) {
+    if (!out || n_samples < 2 || n_pretrigger < 0 || n_pretrigger >= n_samples || !(fs > 0) ||
+        !phi_td || !(vscale != 0.0) || !(w > 0)) {
+        ofx_set_error("ofx_trigger_create: bad argument");
+        return OFX_ERR_ARG;
+    }
+    int rc = create_common(out, n_samples, n_pretrigger, fs, 1, 1, phi_td, device);
+    if (rc) return rc;
+    (*out)->vscale = vscale;
+    (*out)->w = w;
+    (*out)->iw[0] = 1.0 / vscale;
+    (*out)->wm[0] = w;
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_create_nxm(ofx_trigger** out, int n_samples, int n_pretrigger,
+                                      double fs, int n_chan, int n_amp, const double* phi_td,
+                                      const double* iw, const double* w, int device) {
+    if (!out || n_samples < 2 || n_pretrigger < 0 || n_pretrigger >= n_samples || !(fs > 0) ||
+        n_chan < 1 || n_chan > TRIG_MAX || n_amp < 1 || n_amp > TRIG_MAX || !phi_td || !iw || !w) {
+        ofx_set_error("ofx_trigger_create_nxm: bad argument (1..%d channels and amplitudes)",
+                      TRIG_MAX);
+        return OFX_ERR_ARG;
+    }
+    int rc = create_common(out, n_samples, n_pretrigger, fs, n_chan, n_amp, phi_td, device);
+    if (rc) return rc;
+    ofx_trigger* t = *out;
+    for (int i = 0; i < n_amp; ++i)
+        for (int j = 0; j < n_amp; ++j) {
+            t->iw[i * TRIG_MAX + j] = iw[i * n_amp + j];
+            t->wm[i * TRIG_MAX + j] = w[i * n_amp + j];
+        }
+    t->vscale = 1.0 / t->iw[0];
+    t->w = t->wm[0];
     return OFX_OK;
 }
 
@@ -266,74 +377,111 @@ extern "C" int ofx_trigger_destroy(ofx_trigger* t) {
     if (t->info) rocfft_execution_info_destroy(t->info);
     void* bufs[] = {t->d_hfft, t->d_xpad, t->d_spec, t->d_yblk, t->d_filt, t->d_dchi, t->d_scan,
                     t->d_key, t->d_tmp, t->d_stage, t->d_count, t->d_oidx, t->d_odchi, t->d_oamp,
-                    t->d_work};
+                    t->d_work, t->d_acc, t->d_vtd};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete t;
     return OFX_OK;
 }
 
-extern "C" int ofx_trigger_update_trace(ofx_trigger* t, const void* x, int dtype, long long n,
-                                        int mem, double scale, double offset, int padding,
-                                        void* stream) {
-    if (!t || !x || n < 1 || (dtype != 0 && dtype != 1) || n > 2000000000LL) {
-        ofx_set_error("ofx_trigger_update_trace: bad argument");
+extern "C" int ofx_trigger_update_traces(ofx_trigger* t, const void* x, int dtype, long long n,
+                                         int mem, const double* scale, const double* offset,
+                                         int padding, void* stream) {
+    if (!t || !x || n < 1 || (dtype != 0 && dtype != 1) || n > 2000000000LL ||
+        (dtype == 1 && (!scale || !offset))) {
+        ofx_set_error("ofx_trigger_update_traces: bad argument");
         return OFX_ERR_ARG;
     }
     OFX_HIP(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream;
-    const int N = t->N, P = t->P, H = t->H, K = P / 2 + 1;
+    const int N = t->N, P = t->P, H = t->H, K = P / 2 + 1, C = t->C, M = t->M;
     const long long nfull_needed = n + (N - 1) / 2;             // full-conv samples used
     const long long nblk = (nfull_needed + H - 1) / H;
     const long long total = nblk * P;                            // gathered blocks
     const size_t esz = dtype == 0 ? 4 : 2;
-    const void* d_x = x;
+    const char* d_x = (const char*)x;
     if (mem == OFX_MEM_HOST) {
-        if (t->stage_bytes < (size_t)n * esz) {
+        const size_t want = (size_t)C * n * esz;
+        if (t->stage_bytes < want) {
             if (t->d_stage) (void)hipFree(t->d_stage);
             t->d_stage = nullptr;
             t->stage_bytes = 0;
-            OFX_HIP(hipMalloc(&t->d_stage, (size_t)n * esz));
-            t->stage_bytes = (size_t)n * esz;
+            OFX_HIP(hipMalloc(&t->d_stage, want));
+            t->stage_bytes = want;
         }
-        OFX_HIP(hipMemcpyAsync(t->d_stage, x, (size_t)n * esz, hipMemcpyHostToDevice, st));
-        d_x = t->d_stage;
+        OFX_HIP(hipMemcpyAsync(t->d_stage, x, want, hipMemcpyHostToDevice, st));
+        d_x = (const char*)t->d_stage;
     }
     int rc;
     if ((rc = grow(&t->d_xpad, &t->xpad_elems, (size_t)total))) return rc;
-    if ((rc = grow(&t->d_spec, &t->spec_elems, (size_t)nblk * K))) return rc;
+    if ((rc = grow(&t->d_spec, &t->spec_elems, (size_t)C * nblk * K))) return rc;
     if ((rc = grow(&t->d_yblk, &t->yblk_elems, (size_t)nblk * P))) return rc;
     if (t->trace_elems < (size_t)n) {
         if (t->d_filt) (void)hipFree(t->d_filt);
         if (t->d_dchi) (void)hipFree(t->d_dchi);
         t->d_filt = t->d_dchi = nullptr;
         t->trace_elems = 0;
-        OFX_HIP(hipMalloc(&t->d_filt, (size_t)n * sizeof(float)));
+        OFX_HIP(hipMalloc(&t->d_filt, (size_t)M * n * sizeof(float)));
         OFX_HIP(hipMalloc(&t->d_dchi, (size_t)n * sizeof(float)));
         t->trace_elems = (size_t)n;
     }
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_pad<float>, dim3(blocks_for(total)), dim3(TB), 0, st,
-                           (const float*)d_x, n, N - 1, P, H, total, 1.0f, 0.0f, t->d_xpad);
-    else
-        hipLaunchKernelGGL(k_pad<int16_t>, dim3(blocks_for(total)), dim3(TB), 0, st,
-                           (const int16_t*)d_x, n, N - 1, P, H, total, (float)scale,
-                           (float)offset, t->d_xpad);
     if ((rc = make_plans(t, nblk, st))) return rc;
-    void* in1[1] = {t->d_xpad};
-    void* out1[1] = {t->d_spec};
-    OFX_FFT(rocfft_execute(t->r2c, in1, out1, t->info));
-    hipLaunchKernelGGL(k_mul, dim3(blocks_for(nblk * K)), dim3(TB), 0, st, t->d_spec, t->d_hfft,
-                       K, nblk * K);
-    void* in2[1] = {t->d_spec};
-    void* out2[1] = {t->d_yblk};
-    OFX_FFT(rocfft_execute(t->c2r, in2, out2, t->info));
-    hipLaunchKernelGGL(k_dchi2, dim3(blocks_for(n)), dim3(TB), 0, st, t->d_yblk, n, N, P, H,
-                       (float)(1.0 / t->vscale), (float)t->w, padding, t->d_filt, t->d_dchi);
+    for (int b = 0; b < C; ++b) {
+        const char* xb = d_x + (size_t)b * n * esz;
+        if (dtype == 0)
+            hipLaunchKernelGGL(k_pad<float>, dim3(blocks_for(total)), dim3(TB), 0, st,
+                               (const float*)xb, n, N - 1, P, H, total, 1.0f, 0.0f, t->d_xpad);
+        else
+            hipLaunchKernelGGL(k_pad<int16_t>, dim3(blocks_for(total)), dim3(TB), 0, st,
+                               (const int16_t*)xb, n, N - 1, P, H, total, (float)scale[b],
+                               (float)offset[b], t->d_xpad);
+        void* in1[1] = {t->d_xpad};
+        void* out1[1] = {t->d_spec + (size_t)b * nblk * K};
+        OFX_FFT(rocfft_execute(t->r2c, in1, out1, t->info));
+    }
+    if (C == 1 && M == 1) {
+        hipLaunchKernelGGL(k_mul, dim3(blocks_for(nblk * K)), dim3(TB), 0, st, t->d_spec,
+                           t->d_hfft, K, nblk * K);
+        void* in2[1] = {t->d_spec};
+        void* out2[1] = {t->d_yblk};
+        OFX_FFT(rocfft_execute(t->c2r, in2, out2, t->info));
+        hipLaunchKernelGGL(k_dchi2, dim3(blocks_for(n)), dim3(TB), 0, st, t->d_yblk, n, N, P, H,
+                           (float)(1.0 / t->vscale), (float)t->w, padding, t->d_filt, t->d_dchi);
+    } else {
+        if ((rc = grow(&t->d_acc, &t->acc_elems, (size_t)nblk * K))) return rc;
+        if ((rc = grow(&t->d_vtd, &t->vtd_elems, (size_t)M * n))) return rc;
+        for (int m = 0; m < M; ++m) {
+            hipLaunchKernelGGL(k_mulacc, dim3(blocks_for(nblk * K)), dim3(TB), 0, st, t->d_spec,
+                               t->d_hfft, C, M, m, K, nblk * K, t->d_acc);
+            void* in2[1] = {t->d_acc};
+            void* out2[1] = {t->d_yblk};
+            OFX_FFT(rocfft_execute(t->c2r, in2, out2, t->info));
+            hipLaunchKernelGGL(k_extract, dim3(blocks_for(n)), dim3(TB), 0, st, t->d_yblk, n, N, P,
+                               H, t->d_vtd + (size_t)m * n);
+        }
+        TrigMat mat;
+        for (int i = 0; i < TRIG_MAX * TRIG_MAX; ++i) {
+            mat.iw[i] = (float)t->iw[i];
+            mat.w[i] = (float)t->wm[i];
+        }
+        hipLaunchKernelGGL(k_combine, dim3(blocks_for(n)), dim3(TB), 0, st, t->d_vtd, n, N, M, mat,
+                           padding, t->d_filt, t->d_dchi);
+    }
     OFX_HIP(hipGetLastError());
     t->n = n;
     t->nblk = nblk;
     return OFX_OK;
+}
+
+extern "C" int ofx_trigger_update_trace(ofx_trigger* t, const void* x, int dtype, long long n,
+                                        int mem, double scale, double offset, int padding,
+                                        void* stream) {
+    if (t && t->C != 1) {
+        ofx_set_error("ofx_trigger_update_trace: %d-channel trigger, use ofx_trigger_update_traces",
+                      t->C);
+        return OFX_ERR_ARG;
+    }
+    return ofx_trigger_update_traces(t, x, dtype, n, mem, &scale, &offset, padding, stream);
 }
 
 extern "C" int ofx_trigger_get_traces(ofx_trigger* t, float* filtered, float* dchi, int mem,
@@ -345,7 +493,8 @@ extern "C" int ofx_trigger_get_traces(ofx_trigger* t, float* filtered, float* dc
     OFX_HIP(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream;
     const hipMemcpyKind kind = mem == OFX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    if (filtered) OFX_HIP(hipMemcpyAsync(filtered, t->d_filt, (size_t)t->n * 4, kind, st));
+    if (filtered)          // [n_amp][n]
+        OFX_HIP(hipMemcpyAsync(filtered, t->d_filt, (size_t)t->M * t->n * 4, kind, st));
     if (dchi) OFX_HIP(hipMemcpyAsync(dchi, t->d_dchi, (size_t)t->n * 4, kind, st));
     OFX_HIP(hipStreamSynchronize(st));
     return OFX_OK;
@@ -377,7 +526,7 @@ extern "C" int ofx_trigger_find(ofx_trigger* t, double chi2_threshold, long long
         t->out_cap = 0;
         OFX_HIP(hipMalloc(&t->d_oidx, (size_t)cap * sizeof(long long)));
         OFX_HIP(hipMalloc(&t->d_odchi, (size_t)cap * sizeof(float)));
-        OFX_HIP(hipMalloc(&t->d_oamp, (size_t)cap * sizeof(float)));
+        OFX_HIP(hipMalloc(&t->d_oamp, (size_t)cap * t->M * sizeof(float)));
         t->out_cap = (size_t)cap;
     }
     int* prev = t->d_scan;
@@ -402,7 +551,7 @@ extern "C" int ofx_trigger_find(ofx_trigger* t, double chi2_threshold, long long
     OFX_HIP(hipMemsetAsync(t->d_count, 0, sizeof(long long), st));
     hipLaunchKernelGGL(k_best, dim3(nb), dim3(TB), 0, st, t->d_dchi, rstart, n, thr, t->d_key);
     hipLaunchKernelGGL(k_emit, dim3(nb), dim3(TB), 0, st, t->d_dchi, t->d_filt, prev, t->d_key, n,
-                       thr, window, cap, t->d_count, t->d_oidx, t->d_odchi, t->d_oamp);
+                       thr, window, cap, t->M, t->d_count, t->d_oidx, t->d_odchi, t->d_oamp);
     OFX_HIP(hipGetLastError());
     long long cnt = 0;
     OFX_HIP(hipMemcpyAsync(&cnt, t->d_count, sizeof(long long), hipMemcpyDeviceToHost, st));
@@ -411,17 +560,19 @@ extern "C" int ofx_trigger_find(ofx_trigger* t, double chi2_threshold, long long
     const long long m = std::min(cnt, cap);
     if (m > 0) {
         std::vector<long long> hi(m);
-        std::vector<float> hd(m), ha(m);
+        const int M = t->M;
+        std::vector<float> hd(m), ha((size_t)m * M);
         OFX_HIP(hipMemcpy(hi.data(), t->d_oidx, (size_t)m * sizeof(long long), hipMemcpyDeviceToHost));
         OFX_HIP(hipMemcpy(hd.data(), t->d_odchi, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
-        OFX_HIP(hipMemcpy(ha.data(), t->d_oamp, (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+        OFX_HIP(hipMemcpy(ha.data(), t->d_oamp, (size_t)m * M * sizeof(float),
+                          hipMemcpyDeviceToHost));
         std::vector<long long> order(m);
         for (long long i = 0; i < m; ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](long long a, long long b) { return hi[a] < hi[b]; });
         for (long long i = 0; i < m; ++i) {
             index[i] = hi[order[i]];
             dchi_out[i] = hd[order[i]];
-            amp_out[i] = ha[order[i]];
+            for (int a = 0; a < M; ++a) amp_out[i * M + a] = ha[order[i] * M + a];
         }
     }
     if (cnt > cap) {

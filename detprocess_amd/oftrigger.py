@@ -33,27 +33,31 @@ class OptimumFilterTrigger:
                  trigger_name=None, ignored_frequency_peaks=None, ignore_harmonics=False,
                  device=0):
         template = np.asarray(template, dtype=np.float64)
-        noisecsd = np.asarray(noisecsd, dtype=np.float64)
-        # accepted shapes as oftrigger.py:409-441, restricted to N = M = 1
-        if template.ndim == 3:
-            if template.shape[0] != 1 or template.shape[1] != 1:
-                raise NotImplementedError("only the 1 channel x 1 amplitude trigger is on the GPU")
-            template = template[0, 0]
+        noisecsd = np.asarray(noisecsd)
+        # shapes as oftrigger.py:409-441: template -> [channels, amplitudes, samples],
+        # csd -> [channels, channels, frequencies]
+        if template.ndim == 1:
+            template = template.reshape(1, 1, -1)
         elif template.ndim == 2:
             if 1 not in template.shape:
                 raise ValueError(f"Template is shaped as {template.shape}. It should be (N, M, "
                                  "samples) or (samples,) or (1, samples) or (samples, 1).")
-            template = template.reshape(-1)
-        if noisecsd.ndim == 3:
-            if noisecsd.shape[0] != 1 or noisecsd.shape[1] != 1:
-                raise NotImplementedError("only the 1 channel x 1 amplitude trigger is on the GPU")
-            noisecsd = noisecsd[0, 0]
+            template = template.reshape(1, 1, -1)
+        elif template.ndim != 3:
+            raise ValueError(f"Template is shaped as {template.shape}. It should be (N, M, "
+                             "samples) or (samples,) or (1, samples) or (samples, 1).")
+        if noisecsd.ndim == 1:
+            noisecsd = noisecsd.reshape(1, 1, -1)
         elif noisecsd.ndim == 2:
             if 1 not in noisecsd.shape:
                 raise ValueError(f"Noise CSD is shaped as {noisecsd.shape}. Should be (N, M, "
                                  "frequencies) or (frequencies,) or (1, frequencies) or "
                                  "(frequencies, 1).")
-            noisecsd = noisecsd.reshape(-1)
+            noisecsd = noisecsd.reshape(1, 1, -1)
+        elif noisecsd.ndim != 3:
+            raise ValueError(f"Noise CSD is shaped as {noisecsd.shape}. Should be (N, M, "
+                             "frequencies) or (frequencies,) or (1, frequencies) or "
+                             "(frequencies, 1).")
         self._fs = float(fs)
         self._pretrigger_samples = int(pretrigger_samples)
         self._trigger_channel = (trigger_channel if isinstance(trigger_channel, str)
@@ -64,29 +68,59 @@ class OptimumFilterTrigger:
         self._template = template
         self._nb_samples = template.shape[-1]
         self._posttrigger_samples = self._nb_samples - self._pretrigger_samples
-        self._n_channels = 1
-        self._m_amplitudes = 1
+        self._n_channels, _, self._f_frequencies = noisecsd.shape
+        self._m_amplitudes = template.shape[1]
+        if template.shape[0] != self._n_channels or noisecsd.shape[1] != self._n_channels:
+            raise ValueError(f"ERROR: template {template.shape} and csd {noisecsd.shape} do not "
+                             "describe the same channels")
         self._t_times = self._nb_samples
         self._trigger_index_shift = self._pretrigger_samples - self._nb_samples // 2
-        # filter precompute (host, fp64)
-        tables = build_filter(template, noisecsd, self._fs, self._pretrigger_samples, "AC",
-                              ignored_frequency_peaks, ignore_harmonics)
-        J = apply_coupling_and_notches(noisecsd, self._fs, "AC", ignored_frequency_peaks,
-                                       ignore_harmonics)
-        S = np.fft.fft(template)
-        with np.errstate(divide="ignore"):
-            phi_fd = np.where(np.isfinite(J), np.conj(S) / J, 0.0)
-        phi_fd[0] = 0.0                                    # oftrigger.py:488
-        self._phi_td = np.ascontiguousarray(np.fft.ifft(phi_fd).real)
-        self._norm = float(np.dot(self._phi_td, template))                # oftrigger.py:493
-        self._w = float(tables.norm)
-        self._resolution = np.array([tables.ampres])
         self._lib = _lib.load()
         self._h = C.c_void_p()
-        _lib.check(self._lib.ofx_trigger_create(
-            C.byref(self._h), int(self._nb_samples), int(self._pretrigger_samples), self._fs,
-            self._phi_td.ctypes.data, float(tables.norm) * self._fs, self._w, int(device)),
-            "ofx_trigger_create")
+        n = self._nb_samples
+        if self._n_channels == 1 and self._m_amplitudes == 1:
+            # filter precompute (host, fp64)
+            t1 = template[0, 0]
+            psd = np.real(noisecsd[0, 0]).astype(np.float64)
+            tables = build_filter(t1, psd, self._fs, self._pretrigger_samples, "AC",
+                                  ignored_frequency_peaks, ignore_harmonics)
+            J = apply_coupling_and_notches(psd, self._fs, "AC", ignored_frequency_peaks,
+                                           ignore_harmonics)
+            S = np.fft.fft(t1)
+            with np.errstate(divide="ignore"):
+                phi_fd = np.where(np.isfinite(J), np.conj(S) / J, 0.0)
+            phi_fd[0] = 0.0                                    # oftrigger.py:488
+            self._phi_td = np.ascontiguousarray(np.fft.ifft(phi_fd).real).reshape(1, 1, -1)
+            self._w_matrix = np.array([[float(tables.norm)]])
+            self._iw_matrix = np.array([[1.0 / float(tables.norm)]])
+            self._resolution = np.array([tables.ampres])
+            _lib.check(self._lib.ofx_trigger_create(
+                C.byref(self._h), int(n), int(self._pretrigger_samples), self._fs,
+                self._phi_td.ctypes.data, float(tables.norm) * self._fs,
+                float(tables.norm), int(device)), "ofx_trigger_create")
+        else:
+            if n % 2:
+                raise ValueError("ERROR: the NxM trigger needs an even number of samples")
+            from .ofnxm import build_nxm_filter
+            tab = build_nxm_filter(template, noisecsd, self._fs, self._pretrigger_samples, "AC",
+                                   ignored_frequency_peaks, ignore_harmonics)
+            phi = tab.phi.copy()                               # [m, b, k] one-sided
+            phi[:, :, 0] = 0.0                                 # oftrigger.py:488
+            # ifft(phi).real of the Hermitian spectrum = irfft; stored [channel, amplitude, t]
+            phi_td = np.fft.irfft(phi, n=n, axis=-1)
+            self._phi_td = np.ascontiguousarray(np.transpose(phi_td, (1, 0, 2)))
+            pinv = np.asarray(tab.pinv)
+            self._iw_matrix = pinv
+            self._w_matrix = np.linalg.inv(pinv)
+            self._resolution = np.sqrt(np.diag(pinv))          # oftrigger.py:496
+            # conv(x, phi_td) = fs q (oracle/ofnxm.py), so amplitudes = P^-1 V_td / fs
+            iw_dev = np.ascontiguousarray(pinv / self._fs)
+            w_dev = np.ascontiguousarray(self._w_matrix)
+            _lib.check(self._lib.ofx_trigger_create_nxm(
+                C.byref(self._h), int(n), int(self._pretrigger_samples), self._fs,
+                int(self._n_channels), int(self._m_amplitudes), self._phi_td.ctypes.data,
+                iw_dev.ctypes.data, w_dev.ctypes.data, int(device)), "ofx_trigger_create_nxm")
+        self._norm = float(np.dot(self._phi_td[0, 0], template[0, 0]))      # oftrigger.py:493
         self._device = int(device)
         self._n = 0
         self._trigger_data = None
@@ -94,7 +128,7 @@ class OptimumFilterTrigger:
 
     # ------------------------------------------------------------ accessors
     def get_phi(self):
-        return self._phi_td.reshape(1, 1, -1)
+        return self._phi_td
 
     def get_norm(self):
         return self._norm
@@ -111,15 +145,14 @@ class OptimumFilterTrigger:
     def _traces(self):
         if self._n == 0:
             return None, None
-        f = np.empty(self._n, dtype=np.float32)
+        f = np.empty((self._m_amplitudes, self._n), dtype=np.float32)
         d = np.empty(self._n, dtype=np.float32)
         _lib.check(self._lib.ofx_trigger_get_traces(self._h, f.ctypes.data, d.ctypes.data,
                                                     _lib.MEM_HOST, None), "ofx_trigger_get_traces")
         return f, d
 
     def get_filtered_trace(self):
-        f, _ = self._traces()
-        return None if f is None else f.reshape(1, -1)
+        return self._traces()[0]
 
     def get_filtered_delta_chi2(self):
         return self._traces()[1]
@@ -135,11 +168,15 @@ class OptimumFilterTrigger:
         if trace is None:
             raise ValueError('ERROR: "trace" or "filtered_trace required!')
         is_np = isinstance(trace, np.ndarray)
-        if trace.ndim == 2:
-            if trace.shape[0] != 1:
-                raise ValueError(f'ERROR: "trace" has shape {tuple(trace.shape)}, but we have '
-                                 f"{self._n_channels} channels!")
-            trace = trace.reshape(-1)
+        nc = self._n_channels
+        if trace.ndim == 1:
+            trace = trace.reshape(1, -1)
+        if trace.ndim != 2 or trace.shape[0] != nc:
+            raise ValueError(f'ERROR: "trace" has shape {tuple(trace.shape)}, but we have '
+                             f"{nc} channels!")
+        sc = np.ascontiguousarray(np.broadcast_to(np.asarray(
+            1.0 if adc_scale is None else adc_scale, dtype=np.float64), (nc,)))
+        of = np.ascontiguousarray(np.broadcast_to(np.asarray(adc_offset, dtype=np.float64), (nc,)))
         if is_np:
             if trace.dtype == np.int16:
                 if adc_scale is None:
@@ -165,10 +202,10 @@ class OptimumFilterTrigger:
                 dtype = 0
             ptr, mem = x.data_ptr(), _lib.MEM_DEVICE
             stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        n = int(x.shape[0])
-        _lib.check(self._lib.ofx_trigger_update_trace(
-            self._h, ptr, dtype, n, mem, float(adc_scale or 1.0), float(adc_offset),
-            int(bool(padding)), stream), "ofx_trigger_update_trace")
+        n = int(x.shape[-1])
+        _lib.check(self._lib.ofx_trigger_update_traces(
+            self._h, ptr, dtype, n, mem, sc.ctypes.data, of.ctypes.data, int(bool(padding)),
+            stream), "ofx_trigger_update_traces")
         if not is_np:
             import torch
             torch.cuda.current_stream().synchronize()       # x must outlive the kernels
@@ -217,7 +254,7 @@ class OptimumFilterTrigger:
         while True:
             idx = np.empty(cap, dtype=np.int64)
             dchi = np.empty(cap, dtype=np.float32)
-            amp = np.empty(cap, dtype=np.float32)
+            amp = np.empty((cap, self._m_amplitudes), dtype=np.float32)
             cnt = C.c_longlong()
             rc = self._lib.ofx_trigger_find(self._h, chi2_threshold, pileup_window,
                                             idx.ctypes.data, dchi.ctypes.data, amp.ctypes.data,
@@ -237,9 +274,11 @@ class OptimumFilterTrigger:
             "trigger_pileup_window": [pileup_window] * m,
             "trigger_threshold_sigma": [thresh] * m,
             "trigger_type": [4] * m,
-            "trigger_amplitude_0": [float(v) for v in amp[:m]],
-            "trigger_amplitude": [float(v) for v in amp[:m]],
         }
+        for iamp in range(self._m_amplitudes):                          # oftrigger.py:926-929
+            data[f"trigger_amplitude_{iamp}"] = [float(v) for v in amp[:m, iamp]]
+        if self._m_amplitudes == 1:
+            data["trigger_amplitude"] = [float(v) for v in amp[:m, 0]]
         if m > 0:
             data["trigger_channel"] = [str(self._trigger_name)] * m
         self._trigger_data = {self._trigger_name: dict(data)}

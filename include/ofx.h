@@ -254,6 +254,17 @@ int ofx_trigger_create(ofx_trigger** out, int n_samples, int n_pretrigger, doubl
 int ofx_trigger_destroy(ofx_trigger* trig);
 
 /*
+ * N channels x M amplitudes (oftrigger.py:407-499, n_chan, n_amp <= 4): phi_td fp64
+ * [n_chan][n_amp][n_samples] = ifft(phi).real per (channel, amplitude) with the DC bin zeroed;
+ * iw [n_amp][n_amp] maps the summed convolutions onto amplitudes, filtered = iw V_td
+ * (the iweight matrix times the scale of phi), w [n_amp][n_amp] is the weight matrix,
+ * delta_chi2 = filtered^T w filtered (oftrigger.py:656-671).
+ */
+int ofx_trigger_create_nxm(ofx_trigger** out, int n_samples, int n_pretrigger, double fs,
+                           int n_chan, int n_amp, const double* phi_td, const double* iw,
+                           const double* w, int device);
+
+/*
  * update_trace: FIR-filter a continuous stream ('same'-mode linear convolution,
  * scipy.signal.oaconvolve in the reference; overlap-save with batched rocFFT
  * here) and form delta chi2; padding != 0 zeroes delta chi2 within n_samples of
@@ -265,6 +276,11 @@ int ofx_trigger_destroy(ofx_trigger* trig);
 int ofx_trigger_update_trace(ofx_trigger* trig, const void* stream_data, int dtype,
                              long long n, int mem, double scale, double offset, int padding,
                              void* stream);
+/* N x M form: stream_data is [n_chan][n]; scale / offset per channel (read for dtype 1);
+ * the filtered traces are kept as [n_amp][n] */
+int ofx_trigger_update_traces(ofx_trigger* trig, const void* stream_data, int dtype, long long n,
+                              int mem, const double* scale, const double* offset, int padding,
+                              void* stream);
 int ofx_trigger_get_traces(ofx_trigger* trig, float* filtered, float* delta_chi2, int mem,
                            void* stream);
 
@@ -275,7 +291,8 @@ int ofx_trigger_get_traces(ofx_trigger* trig, float* filtered, float* delta_chi2
  * (first maximum).  Outputs (HOST arrays of capacity max_triggers, ascending
  * index): index of the maximum in the stream (WITHOUT the pretrigger shift of
  * oftrigger.py:1005, which the caller adds), its delta chi2 and its filtered
- * amplitude.  *n_triggers receives the number found (may exceed max_triggers:
+ * amplitude(s) (amplitude array: max_triggers x n_amp floats, trigger-major).
+ * *n_triggers receives the number found (may exceed max_triggers:
  * then only the first max_triggers are written and OFX_ERR_ARG is returned).
  */
 int ofx_trigger_find(ofx_trigger* trig, double chi2_threshold, long long pileup_window,

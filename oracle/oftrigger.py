@@ -1,5 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement (fp64 NumPy / SciPy) of the continuous-data
-optimal-filter trigger of detprocess, single channel x single amplitude:
+optimal-filter trigger of detprocess (``OFTrigger``: single channel x single amplitude;
+``OFTriggerNxM``: N channels x M amplitudes):
 
     OptimumFilterTrigger.__init__          detprocess/core/oftrigger.py:384-499
     OptimumFilterTrigger.update_trace      detprocess/core/oftrigger.py:588-679
@@ -111,3 +112,65 @@ class OFTrigger:
             for k in ("trigger_index", "trigger_time", "trigger_delta_chi2", "trigger_amplitude"):
                 out[k] = out[k][keep]
         return out
+
+
+class OFTriggerNxM:
+    """N channels x M amplitudes (oftrigger.py:407-499, 649-679, 926-1019).  phi, weight and
+    iweight are QETpy's (unpinned, restated as in oracle/ofnxm.py): phi_bm(k) = sum_a conj(S_am)
+    Ci_ab with the DC bin zeroed, weight = P, and iweight x (scale of phi) = P^-1 / fs so that
+    the filtered trace of sum_m A_m template_m equals A at the pulse."""
+
+    def __init__(self, fs, templates, csd, pretrigger_samples, ignored_frequency_peaks=None,
+                 ignore_harmonics=False):
+        from . import ofnxm
+        self.fs = float(fs)
+        self.filt = ofnxm.NxMFilter(templates, csd, fs, pretrigger_samples, "AC",
+                                    ignored_frequency_peaks, ignore_harmonics)
+        self.C, self.M, self.N = self.filt.C, self.filt.M, self.filt.N
+        self.pre = int(pretrigger_samples)
+        phi_fd = np.transpose(self.filt.phi, (2, 1, 0)).copy()        # [b, m, k]
+        phi_fd[:, :, 0] = 0.0                                         # oftrigger.py:488
+        self.phi_td = np.fft.ifft(phi_fd, axis=2).real               # oftrigger.py:489
+        self.w_matrix = self.filt.P
+        self.iw_matrix = self.filt.Pinv
+        self.resolution = np.sqrt(np.diag(self.iw_matrix))            # oftrigger.py:496
+        self.index_shift = self.pre - self.N // 2
+        self.filtered = None
+        self.delta_chi2 = None
+
+    def update_trace(self, trace, padding=True):
+        x = np.asarray(trace, dtype=np.float64)
+        v_td = np.zeros((self.M, x.shape[-1]))
+        for theta in range(self.M):                                   # oftrigger.py:656-662
+            per_channel = oaconvolve(x, self.phi_td[:, theta, :], mode="same", axes=-1)
+            v_td[theta] = np.sum(per_channel, axis=0)
+        self.filtered = np.einsum("ij,jz->iz", self.iw_matrix / self.fs, v_td)
+        self.delta_chi2 = np.einsum("iz,ij,jz->z", self.filtered, self.w_matrix, self.filtered)
+        if padding:
+            cut = self.N
+            self.delta_chi2[:cut] = 0.0
+            self.delta_chi2[-(cut) + (cut + 1) % 2:] = 0.0
+        return self.filtered, self.delta_chi2
+
+    def find_triggers(self, thresh, pileup_window_msec=None, pileup_window_samples=None):
+        window = 0
+        if pileup_window_msec is not None:
+            window = int(pileup_window_msec * self.fs / 1000)
+        elif pileup_window_samples is not None:
+            window = pileup_window_samples
+        thr = OFTrigger.chi2_threshold(thresh, self.M)
+        trig = np.where(self.delta_chi2 > thr)[0]
+        idx, dchi, amp = [], [], []
+        if len(trig):
+            cuts = np.where((trig[1:] - trig[:-1]) > window)[0] + 1
+            for s, e in zip(np.concatenate(([0], cuts)), np.concatenate((cuts, [len(trig)]))):
+                inds = trig[s:e]
+                i = inds[np.argmax(self.delta_chi2[inds])]
+                idx.append(i + self.index_shift)
+                dchi.append(self.delta_chi2[i])
+                amp.append(self.filtered[:, i])
+        idx = np.asarray(idx, dtype=np.int64)
+        return {"trigger_index": idx, "trigger_time": idx / self.fs,
+                "trigger_delta_chi2": np.asarray(dchi, dtype=np.float64),
+                "trigger_amplitudes": np.asarray(amp, dtype=np.float64).reshape(-1, self.M),
+                "chi2_threshold": thr, "pileup_window": window}

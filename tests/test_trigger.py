@@ -178,3 +178,112 @@ def test_gpu_trigger_reproduces_golden():
         assert {i for i, (dc, a) in got.items() if dc > thr + margin} <= set(want)
         for i in set(want) & set(got):
             assert got[i][1] == pytest.approx(want[i][1], rel=2e-5, abs=2e-5 * float(g["filtered_max"]))
+
+
+# ------------------------------------------------------------------ N channels x M amplitudes
+def _stream_nxm(n, pre, C, M, L, seed, n_pulses=10):
+    from test_ofnxm import make_csd, make_templates
+    rng = np.random.default_rng(seed)
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    trig = ot.OFTriggerNxM(FS, t, csd, pre)
+    x = np.zeros((C, L))
+    nb = L // n + 2
+    for a in range(C):
+        x[a] = synth.coloured_noise(rng, nb, csd[a, a].real, FS).reshape(-1)[:L]
+    onsets = np.sort(rng.integers(2 * n, L - 3 * n, n_pulses))
+    amps = trig.resolution[None, :] * rng.uniform(10, 80, (n_pulses, M))
+    for p, a in zip(onsets, amps):
+        x[:, p:p + n] += np.einsum("m,amn->an", a, t)
+    return t, csd, trig, x, onsets, amps
+
+
+def test_oracle_nxm_trigger_known_answers():
+    """Noise-free N x M pulses: each amplitude vector is recovered at onset + pretrigger + 1
+    (the same one-sample offset as the 1 x 1 arithmetic), and N = M = 1 is the 1 x 1 oracle."""
+    from test_ofnxm import make_csd, make_templates
+    n, pre, C, M, L = 2048, 700, 2, 2, 40000
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    tr = ot.OFTriggerNxM(FS, t, csd, pre)
+    a = np.array([[4e-7, 1e-7], [-2e-7, 3e-7]])
+    x = np.zeros((C, L))
+    for p, av in zip((8000, 25000), a):
+        x[:, p:p + n] += np.einsum("m,amn->an", av, t)
+    tr.update_trace(x)
+    r = tr.find_triggers(5.0, pileup_window_samples=n)
+    assert list(r["trigger_index"]) == [8000 + pre + 1, 25000 + pre + 1]
+    assert np.allclose(r["trigger_amplitudes"], a, rtol=2e-3, atol=1e-3 * np.abs(a).max())
+    # the delta chi2 at the pulse is the chi2 reduction A^T P A
+    want = np.einsum("pi,ij,pj->p", a, tr.w_matrix, a)
+    assert np.allclose(r["trigger_delta_chi2"], want, rtol=5e-3)
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    t1 = ot.OFTrigger(FS, tmpl, psd, pre)
+    tn = ot.OFTriggerNxM(FS, tmpl[None, None], psd[None, None], pre)
+    rng = np.random.default_rng(0)
+    y = synth.coloured_noise(rng, 12, psd, FS).reshape(-1)
+    y[9000:9000 + n] += 30 * t1.resolution * tmpl
+    f1, d1 = t1.update_trace(y)
+    fn, dn = tn.update_trace(y[None, :])
+    assert np.allclose(fn[0], f1, rtol=1e-9, atol=1e-12 * np.abs(f1).max())
+    assert np.allclose(dn, d1, rtol=1e-9, atol=1e-12 * d1.max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,pre,C,M,L", [(4096, 1500, 2, 2, 300000), (2048, 1024, 3, 2, 120001),
+                                         (8192, 4096, 2, 1, 400000)])
+def test_gpu_nxm_trigger_vs_oracle(n, pre, C, M, L):
+    import torch
+    from detprocess_amd import OptimumFilterTrigger
+    t, csd, tr, x, onsets, amps = _stream_nxm(n, pre, C, M, L, seed=n + C)
+    x32 = x.astype(np.float32)
+    filt, dchi = tr.update_trace(x32.astype(np.float64))
+    name = "|".join("abc"[:C])
+    g = OptimumFilterTrigger(list("abc"[:C]), FS, t, csd, pre)
+    assert np.allclose(g.get_resolution(), tr.resolution, rtol=1e-10)
+    assert g.get_phi().shape == (C, M, n)
+    assert np.allclose(g.get_phi(), tr.phi_td, rtol=1e-9, atol=1e-12 * np.abs(tr.phi_td).max())
+    g.update_trace(x32)
+    gf = g.get_filtered_trace().astype(np.float64)
+    gd = g.get_filtered_delta_chi2().astype(np.float64)
+    assert gf.shape == (M, L)
+    scale = np.max(np.abs(filt), axis=1, keepdims=True)
+    assert np.all(np.abs(gf - filt) <= 3e-5 * scale)
+    assert np.all(gd[:n] == 0) and np.all(gd[L - n + 1:] == 0)
+    assert np.max(np.abs(gd - dchi)) <= 6e-5 * np.max(dchi)
+    ref = tr.find_triggers(5.0, pileup_window_samples=2 * n)
+    g.find_triggers(5.0, pileup_window_samples=2 * n)
+    td = g.get_trigger_data()[name]
+    thr = ref["chi2_threshold"]
+    assert g.get_chi2_threshold() == pytest.approx(thr, rel=1e-12)
+    margin = 1e-3 * thr + 6e-5 * np.max(dchi)
+    ri = {int(i): (d, a) for i, d, a in zip(ref["trigger_index"], ref["trigger_delta_chi2"],
+                                             ref["trigger_amplitudes"])}
+    gamp = np.array([td[f"trigger_amplitude_{m}"] for m in range(M)]).T.reshape(-1, M)
+    gi = {int(i): (d, a) for i, d, a in zip(td["trigger_index"], td["trigger_delta_chi2"], gamp)}
+    assert {i for i, (d, a) in ri.items() if d > thr + margin} <= set(gi)
+    assert {i for i, (d, a) in gi.items() if d > thr + margin} <= set(ri)
+    common = set(ri) & set(gi)
+    assert len(common) >= 0.9 * max(len(ri), 1) and len(common) >= 3
+    for i in common:
+        assert np.all(np.abs(gi[i][1] - ri[i][1]) <= 3e-5 * scale[:, 0] + 2e-5 * np.abs(ri[i][1]))
+        assert gi[i][0] == pytest.approx(ri[i][0], rel=1e-4, abs=margin)
+    assert ("trigger_amplitude" in td) == (M == 1)
+    assert td[f"trigger_index_{name}"] == td["trigger_index"]
+    # isolated injected pulses are found one sample after onset + pretrigger (a pulse stays above
+    # threshold for about a trace length either side, and the window merges gaps up to 2 n)
+    found = np.array(td["trigger_index"])
+    for p in onsets:
+        if np.min(np.abs(onsets[onsets != p] - p)) > 6 * n:
+            assert np.sum(np.abs(found - (p + pre + 1)) <= 3) == 1
+    # device-resident and int16 inputs
+    g.update_trace(torch.as_tensor(x32, device="cuda:0"))
+    assert np.array_equal(g.get_filtered_trace(), gf.astype(np.float32))
+    sc = np.max(np.abs(x32), axis=1) / 30000.0
+    adc = np.round(x32 / sc[:, None]).astype(np.int16)
+    g.update_trace(adc, adc_scale=sc, adc_offset=np.zeros(C))
+    tr.update_trace(adc.astype(np.float64) * sc.astype(np.float32)[:, None])
+    assert np.all(np.abs(g.get_filtered_trace() - tr.filtered) <= 3e-5 * scale)
+    with pytest.raises(ValueError):
+        g.update_trace(x32[:1] if C > 1 else np.zeros((2, L), dtype=np.float32))
