@@ -113,7 +113,7 @@ class OptimumFilterTrigger:
             self._iw_matrix = pinv
             self._w_matrix = np.linalg.inv(pinv)
             self._resolution = np.sqrt(np.diag(pinv))          # oftrigger.py:496
-            # conv(x, phi_td) = fs q (oracle/ofnxm.py), so amplitudes = P^-1 V_td / fs
+            # conv(x, phi_td)(t) = fs q(t) with q as in ofnxm.py, so amplitudes = P^-1 V_td / fs
             iw_dev = np.ascontiguousarray(pinv / self._fs)
             w_dev = np.ascontiguousarray(self._w_matrix)
             _lib.check(self._lib.ofx_trigger_create_nxm(
