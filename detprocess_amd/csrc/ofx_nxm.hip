@@ -1,9 +1,11 @@
 // ofx_nxm.hip -- N-channel x M-template optimal filter (include/ofx.h, "ofx_nxm";
 // FeatureExtractors.ofnxm, detprocess/core/algorithms.py:141-274).
 //
-// Per event: N real transforms (rocFFT R2C), one pass that folds the N spectra into the M
-// filtered spectra Q_m = sum_b phi_mb V_b and the chi2_0 partial sums (k_nxm_mid), M inverse
-// transforms (C2R), and one reduction per event that scans the rolled window for the maximum
+// Per event: N real transforms done as complex transforms of half the length on the packed
+// traces (z[m] = x[2m] + i x[2m+1], rocFFT C2C), one pass that unpacks the real spectra of the
+// pair (k, N/2 - k), folds the N spectra into the M filtered spectra Q_m = sum_b phi_mb V_b,
+// accumulates chi2_0 and repacks for the inverse (k_nxm_mid), M inverse transforms, and one
+// reduction per event that scans the rolled window for the maximum
 // of q^T P^-1 q and writes amplitudes, t0 and chi2 (k_nxm_search).  All four passes are
 // HBM-bound streaming work; the small per-bin matrix products (N, M <= 4) stay on the VALU.
 #include <hip/hip_runtime.h>
@@ -48,8 +50,8 @@ struct ofx_nxm {
     double pinv[NXM_MAX * NXM_MAX] = {0};
     std::vector<NxmSearch> searches;
     float* d_x = nullptr;       // [max_batch, C, N] gathered channels (when needed)
-    float2* d_spec = nullptr;   // [max_batch, C, K]
-    float2* d_q = nullptr;      // [max_batch, M, K]
+    float2* d_spec = nullptr;   // [max_batch, C, N/2] packed spectra
+    float2* d_q = nullptr;      // [max_batch, M, N/2] repacked filtered spectra
     float* d_qt = nullptr;      // [max_batch, M, N]
     float* d_chi0p = nullptr;   // [max_batch, nblk]
     std::map<long long, NxmFft> fft;   // keyed by events per call
@@ -84,44 +86,74 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// one thread per one-sided bin: Q_m = sum_b phi_mb V_b, chi2_0 partial = sum_ab Re(conj(V_a) Ci_ab V_b)
+// One block per event on the packed spectra Z_b = FFT_{N/2}(z_b).  For the pair (k, p = N/2 - k):
+//   u = Z_k + conj(Z_p), w = Z_k - conj(Z_p), s = i t_k w, t_k = exp(-2 pi i k / N)
+//   V_k = (u - s)/2, conj(V_p) = (u + s)/2                  spectrum of the real trace
+//   Q_m = sum_b phi_mb V_b at k and at p;  chi2_0 += Re(V^H Ci V) at k and at p
+//   Ye = Q_k + conj(Q_p), Yo = (Q_k - conj(Q_p)) conj(t_k)
+//   Z'_k = Ye + i Yo, Z'_p = conj(Ye - i Yo)                inverse FFT_{N/2}: q(2n) + i q(2n+1)
+// k = 0 pairs DC with Nyquist; k = N/4 (N/2 even) pairs with itself.
 template <int C, int M>
 __global__ void __launch_bounds__(TB)
-k_nxm_mid(int K, int nblk, const float2* __restrict__ phi, const float2* __restrict__ icov,
+k_nxm_mid(int Mh, int N, int K, const float2* __restrict__ phi, const float2* __restrict__ icov,
           const float2* __restrict__ spec, float2* __restrict__ q, float* __restrict__ chi0p) {
     __shared__ float scratch[TB / OFX_WAVE];
-    const long long e = blockIdx.x;
-    const int k = blockIdx.y * TB + threadIdx.x;
+    const size_t e = blockIdx.x;
     float part = 0.0f;
-    if (k < K) {
-        float2 V[C];
+    for (int k = threadIdx.x; k <= Mh / 2; k += TB) {
+        const int p = (k == 0) ? 0 : Mh - k;
+        const int kp = (k == 0) ? Mh : p;               // one-sided bin of the partner
+        float sn, cs;
+        sincospif(-2.0f * (float)k / (float)N, &sn, &cs);
+        float2 vk[C], vp[C];                            // V_k, V_p
 #pragma unroll
-        for (int b = 0; b < C; ++b) V[b] = spec[((size_t)e * C + b) * K + k];
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            float2 acc = make_float2(0.0f, 0.0f);
-#pragma unroll
-            for (int b = 0; b < C; ++b) {
-                const float2 t = cmulf(phi[((size_t)m * C + b) * K + k], V[b]);
-                acc.x += t.x;
-                acc.y += t.y;
+        for (int b = 0; b < C; ++b) {
+            const float2 zk = spec[(e * C + b) * Mh + k], zp = spec[(e * C + b) * Mh + p];
+            if (k == 0) {
+                vk[b] = make_float2(zk.x + zk.y, 0.0f);
+                vp[b] = make_float2(zk.x - zk.y, 0.0f);
+            } else {
+                const float2 u = make_float2(zk.x + zp.x, zk.y - zp.y);
+                const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
+                const float2 sv = make_float2(-(cs * w.y + sn * w.x), cs * w.x - sn * w.y);
+                vk[b] = make_float2(0.5f * (u.x - sv.x), 0.5f * (u.y - sv.y));
+                vp[b] = make_float2(0.5f * (u.x + sv.x), -0.5f * (u.y + sv.y));
             }
-            q[((size_t)e * M + m) * K + k] = acc;
         }
 #pragma unroll
         for (int a = 0; a < C; ++a) {
-            float2 r = make_float2(0.0f, 0.0f);
+            float2 rk = make_float2(0.0f, 0.0f), rp = make_float2(0.0f, 0.0f);
 #pragma unroll
             for (int b = 0; b < C; ++b) {
-                const float2 t = cmulf(icov[((size_t)a * C + b) * K + k], V[b]);
-                r.x += t.x;
-                r.y += t.y;
+                const float2 tk = cmulf(icov[((size_t)a * C + b) * K + k], vk[b]);
+                const float2 tp = cmulf(icov[((size_t)a * C + b) * K + kp], vp[b]);
+                rk.x += tk.x; rk.y += tk.y;
+                rp.x += tp.x; rp.y += tp.y;
             }
-            part += V[a].x * r.x + V[a].y * r.y;       // Re(conj(V_a) r)
+            part += vk[a].x * rk.x + vk[a].y * rk.y;
+            if (kp != k) part += vp[a].x * rp.x + vp[a].y * rp.y;
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float2 qk = make_float2(0.0f, 0.0f), qp = make_float2(0.0f, 0.0f);
+#pragma unroll
+            for (int b = 0; b < C; ++b) {
+                const float2 tk = cmulf(phi[((size_t)m * C + b) * K + k], vk[b]);
+                const float2 tp = cmulf(phi[((size_t)m * C + b) * K + kp], vp[b]);
+                qk.x += tk.x; qk.y += tk.y;
+                qp.x += tp.x; qp.y += tp.y;
+            }
+            if (k == 0) qk.y = qp.y = 0.0f;     // DC and Nyquist of a real sequence: real parts only
+            const float2 ye = make_float2(qk.x + qp.x, qk.y - qp.y);      // Q_k + conj(Q_p)
+            const float2 d = make_float2(qk.x - qp.x, qk.y + qp.y);       // Q_k - conj(Q_p)
+            const float2 yo = make_float2(d.x * cs + d.y * sn, d.y * cs - d.x * sn);
+            float2* zo = q + (e * M + m) * Mh;
+            zo[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
+            if (p != k) zo[p] = make_float2(ye.x + yo.y, -(ye.y - yo.x));
         }
     }
     part = ofx_block_sum(part, scratch);
-    if (threadIdx.x == 0) chi0p[(size_t)e * nblk + blockIdx.y] = part;
+    if (threadIdx.x == 0) chi0p[e] = part;
 }
 
 template <int M>
@@ -224,13 +256,13 @@ int get_fft(ofx_nxm* p, long long nb, hipStream_t st, NxmFft** out) {
             setup_done = true;
         }
         NxmFft f;
-        const size_t len = (size_t)p->N;
+        const size_t len = (size_t)p->N / 2;             // packed complex points
         OFX_FFT(rocfft_plan_create(&f.fwd, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_forward, rocfft_precision_single, 1,
-                                   &len, (size_t)nb * p->C, nullptr));
+                                   rocfft_transform_type_complex_forward, rocfft_precision_single,
+                                   1, &len, (size_t)nb * p->C, nullptr));
         OFX_FFT(rocfft_plan_create(&f.inv, rocfft_placement_notinplace,
-                                   rocfft_transform_type_real_inverse, rocfft_precision_single, 1,
-                                   &len, (size_t)nb * p->M, nullptr));
+                                   rocfft_transform_type_complex_inverse, rocfft_precision_single,
+                                   1, &len, (size_t)nb * p->M, nullptr));
         size_t w1 = 0, w2 = 0;
         OFX_FFT(rocfft_plan_get_work_buffer_size(f.fwd, &w1));
         OFX_FFT(rocfft_plan_get_work_buffer_size(f.inv, &w2));
@@ -255,11 +287,11 @@ int get_fft(ofx_nxm* p, long long nb, hipStream_t st, NxmFft** out) {
 }
 
 template <int C>
-void launch_mid(ofx_nxm* p, long long nb, int nblk, hipStream_t st) {
-    const dim3 grid((unsigned)nb, (unsigned)nblk);
-#define MID(MM)                                                                          \
-    hipLaunchKernelGGL((k_nxm_mid<C, MM>), grid, dim3(TB), 0, st, p->K, nblk, p->d_phi,  \
-                       p->d_icov, p->d_spec, p->d_q, p->d_chi0p)
+void launch_mid(ofx_nxm* p, long long nb, hipStream_t st) {
+    const dim3 grid((unsigned)nb);
+#define MID(MM)                                                                            \
+    hipLaunchKernelGGL((k_nxm_mid<C, MM>), grid, dim3(TB), 0, st, p->N / 2, p->N, p->K,    \
+                       p->d_phi, p->d_icov, p->d_spec, p->d_q, p->d_chi0p)
     switch (p->M) {
         case 1: MID(1); break;
         case 2: MID(2); break;
@@ -272,11 +304,12 @@ void launch_mid(ofx_nxm* p, long long nb, int nblk, hipStream_t st) {
 int process_device(ofx_nxm* p, const float* traces, const uint8_t* valid, long long nb,
                    float* out, hipStream_t st) {
     const int N = p->N, K = p->K, C = p->C, M = p->M;
-    const int nblk = (K + TB - 1) / TB;
+    const int nblk = 1;                                  // chi2_0: one partial per event
     const size_t mb = (size_t)p->max_batch;
     int rc;
-    if ((rc = grow_to(&p->d_spec, mb * C * K))) return rc;
-    if ((rc = grow_to(&p->d_q, mb * M * K))) return rc;
+    (void)K;
+    if ((rc = grow_to(&p->d_spec, mb * C * (N / 2)))) return rc;
+    if ((rc = grow_to(&p->d_q, mb * M * (N / 2)))) return rc;
     if ((rc = grow_to(&p->d_qt, mb * M * N))) return rc;
     if ((rc = grow_to(&p->d_chi0p, mb * nblk))) return rc;
     bool identity = p->n_total == C;
@@ -295,10 +328,10 @@ int process_device(ofx_nxm* p, const float* traces, const uint8_t* valid, long l
     void* out1[1] = {(void*)p->d_spec};
     OFX_FFT(rocfft_execute(f->fwd, in1, out1, f->info));
     switch (C) {
-        case 1: launch_mid<1>(p, nb, nblk, st); break;
-        case 2: launch_mid<2>(p, nb, nblk, st); break;
-        case 3: launch_mid<3>(p, nb, nblk, st); break;
-        default: launch_mid<4>(p, nb, nblk, st); break;
+        case 1: launch_mid<1>(p, nb, st); break;
+        case 2: launch_mid<2>(p, nb, st); break;
+        case 3: launch_mid<3>(p, nb, st); break;
+        default: launch_mid<4>(p, nb, st); break;
     }
     void* in2[1] = {(void*)p->d_q};
     void* out2[1] = {(void*)p->d_qt};

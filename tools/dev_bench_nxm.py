@@ -17,7 +17,7 @@ def run(n, C, M, B, unconstrained=False):
     t0 = time.perf_counter(); reps = 3
     for _ in range(reps): out = plan.process(ev)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
-    gb = B * n * (C * 4 + C * 8 * 2 + M * 8 * 2 + M * 4 * (2 if unconstrained else 1)) / 1e9
+    gb = B * n * (12 * C + 12 * M + (4 * M if unconstrained else 0)) / 1e9   # x r, Z w+r, Z' w+r, q w (+ r)
     print(f'N={n} {C}x{M} {"unconstrained" if unconstrained else "constrained"}: {B/dt/1e6:.3f} M events/s '
           f'({dt*1e3:.1f} ms, >= {gb/dt:.0f} GB/s of pass traffic)', flush=True)
 run(32768, 2, 2, 8192)
