@@ -93,67 +93,103 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
 //   Ye = Q_k + conj(Q_p), Yo = (Q_k - conj(Q_p)) conj(t_k)
 //   Z'_k = Ye + i Yo, Z'_p = conj(Ye - i Yo)                inverse FFT_{N/2}: q(2n) + i q(2n+1)
 // k = 0 pairs DC with Nyquist; k = N/4 (N/2 even) pairs with itself.
+// A workgroup takes NXM_EV consecutive events so that the filter tables of a bin pair are
+// fetched once (registers / L1) for several events.
+#define NXM_EV 4
 template <int C, int M>
 __global__ void __launch_bounds__(TB)
-k_nxm_mid(int Mh, int N, int K, const float2* __restrict__ phi, const float2* __restrict__ icov,
-          const float2* __restrict__ spec, float2* __restrict__ q, float* __restrict__ chi0p) {
+k_nxm_mid(int Mh, int N, int K, long long n_events, const float2* __restrict__ phi,
+          const float2* __restrict__ icov, const float2* __restrict__ spec, float2* __restrict__ q,
+          float* __restrict__ chi0p) {
     __shared__ float scratch[TB / OFX_WAVE];
-    const size_t e = blockIdx.x;
-    float part = 0.0f;
-    for (int k = threadIdx.x; k <= Mh / 2; k += TB) {
+    const long long e0 = (long long)blockIdx.x * NXM_EV;
+    float part[NXM_EV];
+#pragma unroll
+    for (int i = 0; i < NXM_EV; ++i) part[i] = 0.0f;
+    // the workgroups start at different places of the spectrum: rows lie 4 N bytes apart, and a
+    // lock-step sweep would keep every workgroup on the same few memory channels
+    const int nchunk = (Mh / 2 + TB) / TB;
+    const int first = (int)((blockIdx.x * 7u) % (unsigned)nchunk);
+    for (int j = 0; j < nchunk; ++j) {
+        int c = first + j;
+        if (c >= nchunk) c -= nchunk;
+        const int k = c * TB + threadIdx.x;
+        if (k > Mh / 2) continue;
         const int p = (k == 0) ? 0 : Mh - k;
         const int kp = (k == 0) ? Mh : p;               // one-sided bin of the partner
         float sn, cs;
         sincospif(-2.0f * (float)k / (float)N, &sn, &cs);
-        float2 vk[C], vp[C];                            // V_k, V_p
+        // every load of the bin pair is issued before the first use (the last workgroup
+        // re-reads its last event instead of branching)
+        float2 zks[NXM_EV][C], zps[NXM_EV][C];
 #pragma unroll
-        for (int b = 0; b < C; ++b) {
-            const float2 zk = spec[(e * C + b) * Mh + k], zp = spec[(e * C + b) * Mh + p];
-            if (k == 0) {
-                vk[b] = make_float2(zk.x + zk.y, 0.0f);
-                vp[b] = make_float2(zk.x - zk.y, 0.0f);
-            } else {
-                const float2 u = make_float2(zk.x + zp.x, zk.y - zp.y);
-                const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
-                const float2 sv = make_float2(-(cs * w.y + sn * w.x), cs * w.x - sn * w.y);
-                vk[b] = make_float2(0.5f * (u.x - sv.x), 0.5f * (u.y - sv.y));
-                vp[b] = make_float2(0.5f * (u.x + sv.x), -0.5f * (u.y + sv.y));
+        for (int i = 0; i < NXM_EV; ++i) {
+            const size_t el = (size_t)(e0 + i < n_events ? e0 + i : n_events - 1);
+#pragma unroll
+            for (int b = 0; b < C; ++b) {
+                zks[i][b] = spec[(el * C + b) * Mh + k];
+                zps[i][b] = spec[(el * C + b) * Mh + p];
             }
         }
 #pragma unroll
-        for (int a = 0; a < C; ++a) {
-            float2 rk = make_float2(0.0f, 0.0f), rp = make_float2(0.0f, 0.0f);
+        for (int i = 0; i < NXM_EV; ++i) {
+            const size_t e = (size_t)(e0 + i);
+            const bool live = e0 + i < n_events;
+            float2 vk[C], vp[C];                        // V_k, V_p
 #pragma unroll
             for (int b = 0; b < C; ++b) {
-                const float2 tk = cmulf(icov[((size_t)a * C + b) * K + k], vk[b]);
-                const float2 tp = cmulf(icov[((size_t)a * C + b) * K + kp], vp[b]);
-                rk.x += tk.x; rk.y += tk.y;
-                rp.x += tp.x; rp.y += tp.y;
+                const float2 zk = zks[i][b], zp = zps[i][b];
+                if (k == 0) {
+                    vk[b] = make_float2(zk.x + zk.y, 0.0f);
+                    vp[b] = make_float2(zk.x - zk.y, 0.0f);
+                } else {
+                    const float2 u = make_float2(zk.x + zp.x, zk.y - zp.y);
+                    const float2 w = make_float2(zk.x - zp.x, zk.y + zp.y);
+                    const float2 sv = make_float2(-(cs * w.y + sn * w.x), cs * w.x - sn * w.y);
+                    vk[b] = make_float2(0.5f * (u.x - sv.x), 0.5f * (u.y - sv.y));
+                    vp[b] = make_float2(0.5f * (u.x + sv.x), -0.5f * (u.y + sv.y));
+                }
             }
-            part += vk[a].x * rk.x + vk[a].y * rk.y;
-            if (kp != k) part += vp[a].x * rp.x + vp[a].y * rp.y;
-        }
+            float acc = 0.0f;
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            float2 qk = make_float2(0.0f, 0.0f), qp = make_float2(0.0f, 0.0f);
+            for (int a = 0; a < C; ++a) {
+                float2 rk = make_float2(0.0f, 0.0f), rp = make_float2(0.0f, 0.0f);
 #pragma unroll
-            for (int b = 0; b < C; ++b) {
-                const float2 tk = cmulf(phi[((size_t)m * C + b) * K + k], vk[b]);
-                const float2 tp = cmulf(phi[((size_t)m * C + b) * K + kp], vp[b]);
-                qk.x += tk.x; qk.y += tk.y;
-                qp.x += tp.x; qp.y += tp.y;
+                for (int b = 0; b < C; ++b) {
+                    const float2 tk = cmulf(icov[((size_t)a * C + b) * K + k], vk[b]);
+                    const float2 tp = cmulf(icov[((size_t)a * C + b) * K + kp], vp[b]);
+                    rk.x += tk.x; rk.y += tk.y;
+                    rp.x += tp.x; rp.y += tp.y;
+                }
+                acc += vk[a].x * rk.x + vk[a].y * rk.y;
+                if (kp != k) acc += vp[a].x * rp.x + vp[a].y * rp.y;
             }
-            if (k == 0) qk.y = qp.y = 0.0f;     // DC and Nyquist of a real sequence: real parts only
-            const float2 ye = make_float2(qk.x + qp.x, qk.y - qp.y);      // Q_k + conj(Q_p)
-            const float2 d = make_float2(qk.x - qp.x, qk.y + qp.y);       // Q_k - conj(Q_p)
-            const float2 yo = make_float2(d.x * cs + d.y * sn, d.y * cs - d.x * sn);
-            float2* zo = q + (e * M + m) * Mh;
-            zo[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
-            if (p != k) zo[p] = make_float2(ye.x + yo.y, -(ye.y - yo.x));
+            part[i] += acc;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                float2 qk = make_float2(0.0f, 0.0f), qp = make_float2(0.0f, 0.0f);
+#pragma unroll
+                for (int b = 0; b < C; ++b) {
+                    const float2 tk = cmulf(phi[((size_t)m * C + b) * K + k], vk[b]);
+                    const float2 tp = cmulf(phi[((size_t)m * C + b) * K + kp], vp[b]);
+                    qk.x += tk.x; qk.y += tk.y;
+                    qp.x += tp.x; qp.y += tp.y;
+                }
+                if (k == 0) qk.y = qp.y = 0.0f;   // DC and Nyquist of a real sequence: real parts only
+                const float2 ye = make_float2(qk.x + qp.x, qk.y - qp.y);      // Q_k + conj(Q_p)
+                const float2 d = make_float2(qk.x - qp.x, qk.y + qp.y);       // Q_k - conj(Q_p)
+                const float2 yo = make_float2(d.x * cs + d.y * sn, d.y * cs - d.x * sn);
+                float2* zo = q + (e * M + m) * Mh;
+                if (live) zo[k] = make_float2(ye.x - yo.y, ye.y + yo.x);
+                if (live && p != k) zo[p] = make_float2(ye.x + yo.y, -(ye.y - yo.x));
+            }
         }
     }
-    part = ofx_block_sum(part, scratch);
-    if (threadIdx.x == 0) chi0p[e] = part;
+#pragma unroll
+    for (int i = 0; i < NXM_EV; ++i) {
+        const float sum = ofx_block_sum(part[i], scratch);
+        if (threadIdx.x == 0 && e0 + i < n_events) chi0p[e0 + i] = sum;
+    }
 }
 
 template <int M>
@@ -288,9 +324,9 @@ int get_fft(ofx_nxm* p, long long nb, hipStream_t st, NxmFft** out) {
 
 template <int C>
 void launch_mid(ofx_nxm* p, long long nb, hipStream_t st) {
-    const dim3 grid((unsigned)nb);
+    const dim3 grid((unsigned)((nb + NXM_EV - 1) / NXM_EV));
 #define MID(MM)                                                                            \
-    hipLaunchKernelGGL((k_nxm_mid<C, MM>), grid, dim3(TB), 0, st, p->N / 2, p->N, p->K,    \
+    hipLaunchKernelGGL((k_nxm_mid<C, MM>), grid, dim3(TB), 0, st, p->N / 2, p->N, p->K, nb, \
                        p->d_phi, p->d_icov, p->d_spec, p->d_q, p->d_chi0p)
     switch (p->M) {
         case 1: MID(1); break;
