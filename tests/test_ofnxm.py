@@ -199,6 +199,12 @@ def test_nxm_channel_map_valid_mask_and_device_buffers():
     # device-resident events: same numbers, no host staging
     dev = plan.process(torch.from_numpy(full).cuda(), torch.from_numpy(valid).cuda())
     assert np.array_equal(dev.cpu().numpy(), out)
+    # an empty batch is legal and returns an empty matrix (host and device)
+    assert plan.process(np.zeros((0, 4, n), dtype=np.float32)).shape == (0, plan.row_floats)
+    assert tuple(plan.process(torch.zeros((0, 4, n), device="cuda")).shape) == (0, plan.row_floats)
+    # a batch that is not a multiple of the workgroup's event group, nor of max_batch
+    out13 = plan.process(full[:13], valid[:13])
+    assert np.array_equal(out13, out[:13])
     # empty window -> sentinel record; bad shapes and missing searches raise
     plan.reset_searches()
     with pytest.raises(Exception):
