@@ -366,3 +366,52 @@ a|b:
     assert list(df.columns) == list(df2.columns) and "amp1_of2x2_constrained_ab" in df.columns
     assert np.array_equal(df.to_numpy(), df2.to_numpy())
     assert (df.iloc[4] == -999999.0).all()
+
+
+@pytest.mark.gpu
+def test_nxm_properties_at_full_size():
+    """Size-independent properties on a batch the oracle could not check in seconds (2048 events,
+    2 x 2, 32768 samples, device-resident): exact scaling by powers of two, window consistency,
+    chi2 ordering, circular-shift equivariance."""
+    import torch
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter
+    n, pre, C, M, B = 32768, 16384, 2, 2, 2048
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    tab = build_nxm_filter(t, csd, FS, pre)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ev = torch.randn((B, C, n), device="cuda", generator=g) * 2e-9
+    tt = torch.as_tensor(t, dtype=torch.float32, device="cuda")
+    amp = 1e-7 + torch.rand((B, M), device="cuda", generator=g) * 3e-7     # well above the noise
+    shift = torch.randint(-300, 301, (B,), device="cuda", generator=g)
+    pulses = torch.einsum("bm,amn->ban", amp, tt)
+    idx = (torch.arange(n, device="cuda")[None, :] - shift[:, None]) % n
+    ev += torch.gather(pulses, 2, idx[:, None, :].expand(B, C, n))
+    plan = NxMPlan(tab, max_batch=512)
+    s_nd = plan.add_search("nodelay")
+    s_un = plan.add_search("delay")
+    s_win = plan.add_search("delay", pre - 400, pre + 400)
+    out = plan.process(ev)
+    a_nd, _, c_nd, _ = plan.record(out, s_nd)
+    a_un, t_un, c_un, i_un = plan.record(out, s_un)
+    a_w, t_w, c_w, i_w = plan.record(out, s_win)
+    # the injected delay is found (SNR is high) and the window that contains it changes nothing
+    assert torch.equal(i_un.long(), (pre + shift).long())
+    assert torch.equal(i_w, i_un) and torch.equal(a_w, a_un) and torch.equal(c_w, c_un)
+    assert torch.allclose(a_un, amp, rtol=0.05, atol=2e-8)
+    # a delay fit can only lower chi2; at zero delay both are the same fit
+    assert bool((c_un <= c_nd * (1 + 1e-6)).all())
+    zero = shift == 0
+    if bool(zero.any()):
+        assert torch.allclose(c_un[zero], c_nd[zero], rtol=1e-6)
+    # scaling the events by 4 scales amplitudes by 4 and chi2 by 16, bit for bit
+    out4 = plan.process(ev * 4.0)
+    a4, t4, c4, i4 = plan.record(out4, s_un)
+    assert torch.equal(i4, i_un) and torch.equal(a4, a_un * 4.0) and torch.equal(c4, c_un * 16.0)
+    # rolling every channel by d samples moves the time bin by d and leaves the fit unchanged
+    d = 37
+    outr = plan.process(torch.roll(ev, d, dims=2))
+    ar, tr, cr, ir = plan.record(outr, s_un)
+    assert torch.equal(ir.long(), i_un.long() + d)
+    assert torch.allclose(ar, a_un, rtol=2e-5, atol=1e-4 * float(tab.ampres.max()))
+    assert torch.allclose(cr, c_un, rtol=2e-5)
