@@ -643,3 +643,38 @@ A:
                                     window_max_from_trig_usec=1000)
     e_ref = orc.energyabsorbed(x64, FS, 190.6e-9, 88e-9, 8.8e-3, lo, hi)
     assert np.allclose(df["energyabsorbed_A"], e_ref, rtol=2e-4, atol=1e-6 * np.abs(e_ref).max())
+
+
+@pytest.mark.gpu
+def test_command_line_driver(tmp_path):
+    """scripts/process_features.py: YAML + filter file + events on disk -> numbered feature files."""
+    import importlib.util
+    import os
+    import pandas as pd
+    from detprocess_amd import FeatureProcessing
+    from detprocess_amd.output import read_features
+    n, pre, B = 32768, 16384, 10
+    fd, J = _filter_data(n, pre)
+    tmpl = synth.make_template(n, pre, FS)
+    x, _, _ = synth.make_traces(B * 4, tmpl, J, FS, 1e-9, seed=8, max_delay=100)
+    ev = x.reshape(B, 4, n).astype(np.float32)
+    np.save(tmp_path / "events.npy", ev)
+    fd.save_npz(str(tmp_path / "filter.npz"))
+    yaml_text = YAML
+    (tmp_path / "setup.yaml").write_text(yaml_text)
+    spec = importlib.util.spec_from_file_location(
+        "process_features", os.path.join(os.path.dirname(__file__), "..", "scripts",
+                                         "process_features.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    files = mod.main(["--processing_setup", str(tmp_path / "setup.yaml"), "--filter_file",
+                      str(tmp_path / "filter.npz"), "--events", str(tmp_path / "events.npy"),
+                      "--channels", ",".join(CHANS), "--sample_rate", str(FS), "--save_path",
+                      str(tmp_path / "out"), "--events_per_dump", "6", "--processing_id", "t1"])
+    assert [os.path.basename(f)[-12:] for f in files] == ["_F0001.arrow", "_F0002.arrow"]
+    assert os.path.basename(os.path.dirname(files[0])).startswith("t1_feature_I1_D")
+    got = pd.concat([read_features(f) for f in files], ignore_index=True)
+    want = FeatureProcessing(yaml_text, fd, CHANS, FS).process(ev)
+    assert list(got["event_index"]) == list(range(B))
+    for c in want.columns:
+        assert np.array_equal(got[c].to_numpy(), want[c].to_numpy()), c
