@@ -287,3 +287,50 @@ def test_gpu_nxm_trigger_vs_oracle(n, pre, C, M, L):
     assert np.all(np.abs(g.get_filtered_trace() - tr.filtered) <= 3e-5 * scale)
     with pytest.raises(ValueError):
         g.update_trace(x32[:1] if C > 1 else np.zeros((2, L), dtype=np.float32))
+
+
+@pytest.mark.gpu
+def test_trigger_then_features_on_one_int16_stream():
+    """The stage before the path feeding the path (triggers.py -> features.py in the reference):
+    triggers found on a continuous int16 stream are handed, as trigger indices, to the batched
+    feature driver, which cuts the events out of the same stream on the GPU.  Every injected,
+    isolated pulse comes back with its amplitude and a fitted delay of one sample (the trigger
+    index sits one sample after onset + pretrigger, see oracle/oftrigger.py)."""
+    from detprocess_amd import FeatureProcessing, FilterData, OptimumFilterTrigger
+    n, pre, L = 4096, 2048, 800000
+    tmpl, psd, t, x, onsets, amps = _stream(n, pre, L, seed=6, n_pulses=10)
+    scale = float(np.max(np.abs(x))) / 30000.0
+    adc = np.round(x / scale).astype(np.int16)[None, :]
+    trig = OptimumFilterTrigger("chanA", FS, tmpl, psd, pre)
+    trig.update_trace(adc[0], adc_scale=scale)
+    trig.find_triggers(8.0, pileup_window_samples=2 * n)
+    found = np.array(trig.get_trigger_data()["chanA"]["trigger_index"], dtype=np.int64)
+    fd = FilterData()
+    fd.set_template("chanA", tmpl, sample_rate=FS, pretrigger_length_samples=pre, tag="default")
+    fd.set_psd("chanA", psd, np.fft.fftfreq(n, d=1 / FS), sample_rate=FS, tag="default")
+    yaml_text = """
+chanA:
+    of1x1_constrained:
+        run: True
+        template_tag: default
+        window_min_from_trig_usec: -50
+        window_max_from_trig_usec: 50
+    baseline:
+        run: True
+        window_min_from_start_usec: 0
+        window_max_from_trig_usec: -500
+"""
+    fp = FeatureProcessing(yaml_text, fd, ["chanA"], FS, nb_samples=n, nb_pretrigger_samples=pre)
+    df = fp.process_adc(adc, found, scale, 0.0)
+    assert len(df) == len(found)
+    checked = 0
+    for p, a in zip(onsets, amps):
+        if np.min(np.abs(onsets[onsets != p] - p)) <= 6 * n:
+            continue
+        hit = np.nonzero(np.abs(found - (p + pre + 1)) <= 2)[0]
+        assert len(hit) == 1
+        row = df.iloc[hit[0]]
+        assert row["amp_of1x1_constrained_chanA"] == pytest.approx(a, rel=0.2, abs=3 * t.resolution)
+        assert abs(round(row["t0_of1x1_constrained_chanA"] * FS) + (found[hit[0]] - (p + pre))) <= 1
+        checked += 1
+    assert checked >= 5
