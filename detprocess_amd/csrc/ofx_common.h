@@ -181,6 +181,14 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                     long long n, float* d_out, hipStream_t st);
 int ofx_lds_release(ofx_plan* p);
 
+// ofx_lds.hip: the LDS-resident mixed-radix transform on its own (batched, natural-order rows;
+// lengths 2^a 3^b 5^c that fit in LDS).  create returns OFX_ERR_UNSUPPORTED for other lengths.
+struct OfxLdsFft;
+int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out);
+void ofx_ldsfft_destroy(OfxLdsFft* f);
+int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
+                    hipStream_t st);
+
 // timing helpers
 int ofx_time_begin(ofx_plan* p, hipStream_t st, size_t* idx);
 int ofx_time_end(ofx_plan* p, hipStream_t st, size_t idx);

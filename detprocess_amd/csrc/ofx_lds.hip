@@ -183,6 +183,64 @@ static int pos_of(int k, const LdsGeom& g) {
     return p;
 }
 
+// Batched complex transform of length M with natural-order rows in global memory (the
+// transform of k_lds on its own): forward reads a row into LDS, runs the DIF stages and gathers
+// the bins from their digit-reversed positions; inverse scatters the bins to those positions,
+// runs the DIT stages and writes the row.  Unnormalised, as rocFFT.  Used by the N x M engine
+// for trace lengths where rocFFT falls back to its multi-kernel path.
+template <int BT, bool FWD>
+__global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restrict__ stw,
+                                                const int* __restrict__ pos,
+                                                const float2* __restrict__ in,
+                                                float2* __restrict__ out, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cpx* z = reinterpret_cast<cpx*>(smem);                         // [M]
+    cpx* tw1 = z + g.M;                                            // [ntw]
+    const int tid = threadIdx.x, M = g.M;
+    for (int i = tid; i < g.ntw; i += BT) tw1[i] = mk(stw[i].x, stw[i].y);
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float2* src = in + (size_t)r * M;
+        float2* dst = out + (size_t)r * M;
+        __syncthreads();                                           // readers of the last row
+        for (int m0 = tid; m0 < M; m0 += 8 * BT) {                 // batches of independent loads
+            float2 tmp[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (m0 + i * BT < M) tmp[i] = src[m0 + i * BT];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (m0 + i * BT < M) {
+                    const int m = m0 + i * BT;
+                    z[FWD ? m : pos[m]] = mk(tmp[i].x, tmp[i].y);
+                }
+        }
+        __syncthreads();
+        if constexpr (FWD) {
+            int L = M;
+            for (int i = 0; i < g.nfac; ++i) {
+                stage_any<true>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                L /= g.fac[i];
+                __syncthreads();
+            }
+        } else {
+            int Ls[LDS_MAX_FAC];
+            int L = M;
+            for (int i = 0; i < g.nfac; ++i) {
+                Ls[i] = L;
+                L /= g.fac[i];
+            }
+            for (int i = g.nfac - 1; i >= 0; --i) {
+                stage_any<false>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                __syncthreads();
+            }
+        }
+        for (int m = tid; m < M; m += BT) {
+            const cpx v = z[FWD ? pos[m] : m];
+            dst[m] = make_float2(v.x, v.y);
+        }
+    }
+}
+
 template <int BT, bool PF>
 __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsSlot* __restrict__ slots,
                                             int nslots, const float2* __restrict__ stw,
@@ -688,4 +746,102 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
                   : launch_lds<256, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
     if (bf >= 128) return launch_lds<128, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
     return launch_lds<64, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+}
+
+// ------------------------------------------------------------------ standalone batched FFT
+struct OfxLdsFft {
+    LdsGeom g;
+    float2* d_tw = nullptr;
+    int* d_pos = nullptr;
+    size_t lds = 0;
+    int cu_count = 256;
+};
+
+namespace {
+template <int BT, bool FWD>
+int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_fft<BT, FWD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+        attr_done = true;
+    }
+    int per_cu = (int)((160 * 1024) / f->lds);
+    if (per_cu > 1024 / BT) per_cu = 1024 / BT;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)f->cu_count * per_cu;
+    if (grid > rows) grid = rows;
+    hipLaunchKernelGGL((k_lds_fft<BT, FWD>), dim3((unsigned)grid), dim3(BT), f->lds, st, f->g,
+                       f->d_tw, f->d_pos, in, out, rows);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+}  // namespace
+
+int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
+    std::vector<int> fac;
+    const int M = n_complex;
+    if (M < 8 || !factorize(M, &fac)) return OFX_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)M * 8 + (size_t)stage_twiddle_count(M, fac) * 8;
+    if (lds > LDS_BUDGET) return OFX_ERR_UNSUPPORTED;
+    OfxLdsFft* f = new OfxLdsFft();
+    memset(&f->g, 0, sizeof(f->g));
+    f->g.M = M;
+    f->g.N = 2 * M;
+    f->g.nfac = (int)fac.size();
+    f->lds = lds;
+    int L = M;
+    for (int i = 0; i < f->g.nfac; ++i) {
+        f->g.fac[i] = fac[i];
+        const unsigned stride = (unsigned)(L / fac[i]);
+        f->g.magic[i] = (unsigned)((1ull << 32) / stride) + 1u;
+        f->g.toff[i] = f->g.ntw;
+        if (stride > 1) f->g.ntw += (int)stride;
+        L /= fac[i];
+    }
+    std::vector<float2> t1((size_t)std::max(1, f->g.ntw));
+    L = M;
+    for (int i = 0; i < f->g.nfac; ++i) {
+        const int stride = L / f->g.fac[i];
+        if (stride > 1)
+            for (int j = 0; j < stride; ++j) {
+                const double a1 = -6.283185307179586476925286766559 * (double)j / (double)L;
+                t1[f->g.toff[i] + j] = make_float2((float)std::cos(a1), (float)std::sin(a1));
+            }
+        L /= f->g.fac[i];
+    }
+    std::vector<int> pos((size_t)M);
+    for (int k = 0; k < M; ++k) pos[k] = pos_of(k, f->g);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) f->cu_count = prop.multiProcessorCount;
+    if (hipMalloc(&f->d_tw, t1.size() * sizeof(float2)) != hipSuccess ||
+        hipMalloc(&f->d_pos, pos.size() * sizeof(int)) != hipSuccess ||
+        hipMemcpy(f->d_tw, t1.data(), t1.size() * sizeof(float2), hipMemcpyHostToDevice) !=
+            hipSuccess ||
+        hipMemcpy(f->d_pos, pos.data(), pos.size() * sizeof(int), hipMemcpyHostToDevice) !=
+            hipSuccess) {
+        ofx_set_error("ofx_ldsfft_create: device allocation failed");
+        ofx_ldsfft_destroy(f);
+        return OFX_ERR_HIP;
+    }
+    *out = f;
+    return OFX_OK;
+}
+
+void ofx_ldsfft_destroy(OfxLdsFft* f) {
+    if (!f) return;
+    if (f->d_tw) (void)hipFree(f->d_tw);
+    if (f->d_pos) (void)hipFree(f->d_pos);
+    delete f;
+}
+
+int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
+                    hipStream_t st) {
+    if (rows <= 0) return OFX_OK;
+    const bool big = f->g.M >= 1024;
+    if (forward)
+        return big ? launch_lds_fft<512, true>(f, in, out, rows, st)
+                   : launch_lds_fft<256, true>(f, in, out, rows, st);
+    return big ? launch_lds_fft<512, false>(f, in, out, rows, st)
+               : launch_lds_fft<256, false>(f, in, out, rows, st);
 }

@@ -61,6 +61,8 @@ struct ofx_nxm {
     uint8_t* d_stage_valid = nullptr;
     float* d_stage_out = nullptr;
     size_t stage_out_floats = 0;
+    OfxLdsFft* ldsfft = nullptr;       // non-power-of-two lengths the LDS transform handles
+    bool ldsfft_tried = false;
     int16_t* d_adc = nullptr;          // ofx_nxm_process_adc: staged streams, trigger indices
     size_t adc_elems = 0;
     long long* d_trig = nullptr;
@@ -358,20 +360,42 @@ int process_device(ofx_nxm* p, const float* traces, const uint8_t* valid, long l
                            st, traces, p->n_total, C, idx, N, p->d_x);
         x = p->d_x;
     }
+    // transforms: rocFFT, except for non-power-of-two lengths of the form 2^a 3^b 5^c that fit in
+    // LDS, where rocFFT takes a multi-kernel path and the one-kernel LDS transform is faster
+    if (!p->ldsfft_tried) {
+        p->ldsfft_tried = true;
+        const int Mh = N / 2;
+        if ((Mh & (Mh - 1)) != 0) {
+            const int r = ofx_ldsfft_create(Mh, p->device, &p->ldsfft);
+            if (r != OFX_OK && r != OFX_ERR_UNSUPPORTED) return r;
+        }
+    }
     NxmFft* f = nullptr;
-    if ((rc = get_fft(p, nb, st, &f))) return rc;
-    void* in1[1] = {(void*)x};
-    void* out1[1] = {(void*)p->d_spec};
-    OFX_FFT(rocfft_execute(f->fwd, in1, out1, f->info));
+    if (p->ldsfft) {
+        if ((rc = ofx_ldsfft_exec(p->ldsfft, true, reinterpret_cast<const float2*>(x), p->d_spec,
+                                  nb * C, st)))
+            return rc;
+    } else {
+        if ((rc = get_fft(p, nb, st, &f))) return rc;
+        void* in1[1] = {(void*)x};
+        void* out1[1] = {(void*)p->d_spec};
+        OFX_FFT(rocfft_execute(f->fwd, in1, out1, f->info));
+    }
     switch (C) {
         case 1: launch_mid<1>(p, nb, st); break;
         case 2: launch_mid<2>(p, nb, st); break;
         case 3: launch_mid<3>(p, nb, st); break;
         default: launch_mid<4>(p, nb, st); break;
     }
-    void* in2[1] = {(void*)p->d_q};
-    void* out2[1] = {(void*)p->d_qt};
-    OFX_FFT(rocfft_execute(f->inv, in2, out2, f->info));
+    if (p->ldsfft) {
+        if ((rc = ofx_ldsfft_exec(p->ldsfft, false, p->d_q, reinterpret_cast<float2*>(p->d_qt),
+                                  nb * M, st)))
+            return rc;
+    } else {
+        void* in2[1] = {(void*)p->d_q};
+        void* out2[1] = {(void*)p->d_qt};
+        OFX_FFT(rocfft_execute(f->inv, in2, out2, f->info));
+    }
     NxmParams prm;
     std::memset(&prm, 0, sizeof(prm));
     prm.N = N;
@@ -432,6 +456,7 @@ extern "C" int ofx_nxm_destroy(ofx_nxm* p) {
         if (kv.second.inv) rocfft_plan_destroy(kv.second.inv);
         if (kv.second.info) rocfft_execution_info_destroy(kv.second.info);
     }
+    ofx_ldsfft_destroy(p->ldsfft);
     void* bufs[] = {p->d_phi, p->d_icov, p->d_x, p->d_spec, p->d_q, p->d_qt, p->d_chi0p,
                     p->d_work, p->d_stage_in, p->d_stage_valid, p->d_stage_out, p->d_adc,
                     p->d_trig};
