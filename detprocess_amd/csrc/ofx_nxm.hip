@@ -57,7 +57,8 @@ struct ofx_nxm {
     std::map<long long, NxmFft> fft;   // keyed by events per call
     void* d_work = nullptr;
     size_t work_bytes = 0;
-    float* d_stage_in = nullptr;
+    float* d_stage_in = nullptr;       // [max_batch, n_total, N]; regrown when n_total grows
+    size_t stage_in_floats = 0;
     uint8_t* d_stage_valid = nullptr;
     float* d_stage_out = nullptr;
     size_t stage_out_floats = 0;
@@ -282,6 +283,18 @@ template <typename T>
 int grow_to(T** buf, size_t elems) {
     if (*buf) return OFX_OK;
     OFX_HIP(hipMalloc(reinterpret_cast<void**>(buf), elems * sizeof(T)));
+    return OFX_OK;
+}
+
+// staging buffer of the events: its size follows n_total, which ofx_nxm_set_channels may change
+int ensure_stage_in(ofx_nxm* p, size_t floats, hipStream_t st) {
+    if (p->stage_in_floats >= floats) return OFX_OK;
+    OFX_HIP(hipStreamSynchronize(st));
+    if (p->d_stage_in) (void)hipFree(p->d_stage_in);
+    p->d_stage_in = nullptr;
+    p->stage_in_floats = 0;
+    OFX_HIP(hipMalloc(&p->d_stage_in, floats * sizeof(float)));
+    p->stage_in_floats = floats;
     return OFX_OK;
 }
 
@@ -565,7 +578,7 @@ extern "C" int ofx_nxm_process(ofx_nxm* p, const float* traces, const uint8_t* v
         const uint8_t* d_valid = valid ? valid + b0 : nullptr;
         float* d_out = out + (size_t)b0 * row;
         if (traces_mem == OFX_MEM_HOST) {
-            if ((rc = grow_to(&p->d_stage_in, (size_t)chunk * ev_floats))) return rc;
+            if ((rc = ensure_stage_in(p, (size_t)chunk * ev_floats, st))) return rc;
             OFX_HIP(hipMemcpyAsync(p->d_stage_in, d_in, (size_t)nb * ev_floats * sizeof(float),
                                    hipMemcpyHostToDevice, st));
             d_in = p->d_stage_in;
@@ -648,7 +661,7 @@ extern "C" int ofx_nxm_process_adc(ofx_nxm* p, const int16_t* adc, long long n_s
     }
     const long long chunk = p->max_batch;
     int rc;
-    if ((rc = grow_to(&p->d_stage_in, (size_t)chunk * ev_floats))) return rc;
+    if ((rc = ensure_stage_in(p, (size_t)chunk * ev_floats, st))) return rc;
     if ((rc = grow_to(&p->d_stage_valid, (size_t)chunk))) return rc;
     if (out_mem == OFX_MEM_HOST && p->stage_out_floats < (size_t)chunk * row) {
         OFX_HIP(hipStreamSynchronize(st));

@@ -185,6 +185,10 @@ def test_nxm_channel_map_valid_mask_and_device_buffers():
     full[:, 0] = 1e-6                                         # channels the fit must not touch
     full[:, 2] = -1e-6
     plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=8)
+    # first a call on the bare pair, then the map onto a wider event array (staging regrows)
+    s0 = plan.add_search("delay", pre - 400, pre + 400)
+    bare = plan.process(ev.astype(np.float32))
+    plan.reset_searches()
     plan.set_channels(4, [3, 1])
     sid = plan.add_search("delay", pre - 400, pre + 400)
     valid = np.ones(20, dtype=np.uint8)
@@ -196,6 +200,7 @@ def test_nxm_channel_map_valid_mask_and_device_buffers():
     assert np.all(out[~ok] == -999999.0)
     sub = {k: v[ok] for k, v in ref.items()}
     _check(plan, out[ok], sid, sub, filt)
+    assert s0 == sid and np.array_equal(bare[ok], out[ok])
     # device-resident events: same numbers, no host staging
     dev = plan.process(torch.from_numpy(full).cuda(), torch.from_numpy(valid).cuda())
     assert np.array_equal(dev.cpu().numpy(), out)
