@@ -143,7 +143,8 @@ def _check(plan, out, sid, ref, filt, nodelay=False):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,pre,C,M", [(4096, 2048, 2, 2), (32768, 16384, 2, 2), (25000, 12500, 3, 2),
-                                       (2048, 500, 1, 1), (4096, 2048, 4, 4), (8192, 4096, 2, 3)])
+                                       (2048, 500, 1, 1), (4096, 2048, 4, 4), (8192, 4096, 2, 3),
+                                       (250, 100, 2, 2), (1002, 400, 2, 1)])
 def test_nxm_gpu_matches_oracle(n, pre, C, M):
     from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter, nxm_search_range
     t = make_templates(n, pre, C, M)
