@@ -101,6 +101,14 @@ struct OfxFftPlans {
     size_t work_bytes = 0;
 };
 
+// ofx_lds.hip: the LDS-resident mixed-radix transform on its own (batched, natural-order rows;
+// lengths 2^a 3^b 5^c that fit in LDS).  create returns OFX_ERR_UNSUPPORTED for other lengths.
+struct OfxLdsFft;
+int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out);
+void ofx_ldsfft_destroy(OfxLdsFft* f);
+int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
+                    hipStream_t st);
+
 struct ofx_plan {
     int N = 0, K = 0, pre = 0;
     double fs = 0;
@@ -118,6 +126,8 @@ struct ofx_plan {
 
     // ROCFFT engine buffers (lazy)
     std::map<int, OfxFftPlans> fft;      // keyed by batch
+    OfxLdsFft* ldsfft = nullptr;  // non-power-of-two lengths the LDS transform handles
+    bool ldsfft_tried = false;
     float* d_trace = nullptr;            // [max_batch, N] combined trace (if needed)
     float2* d_spec = nullptr;            // [max_batch, K]
     float2* d_filt = nullptr;            // [max_batch, K]
@@ -180,14 +190,6 @@ bool ofx_lds_supported(int n_samples);
 int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                     long long n, float* d_out, hipStream_t st);
 int ofx_lds_release(ofx_plan* p);
-
-// ofx_lds.hip: the LDS-resident mixed-radix transform on its own (batched, natural-order rows;
-// lengths 2^a 3^b 5^c that fit in LDS).  create returns OFX_ERR_UNSUPPORTED for other lengths.
-struct OfxLdsFft;
-int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out);
-void ofx_ldsfft_destroy(OfxLdsFft* f);
-int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
-                    hipStream_t st);
 
 // timing helpers
 int ofx_time_begin(ofx_plan* p, hipStream_t st, size_t* idx);

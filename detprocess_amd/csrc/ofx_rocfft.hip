@@ -293,6 +293,9 @@ int ofx_rocfft_release(ofx_plan* p) {
         if (f.work) (void)hipFree(f.work);
     }
     p->fft.clear();
+    ofx_ldsfft_destroy(p->ldsfft);
+    p->ldsfft = nullptr;
+    p->ldsfft_tried = false;
     if (p->d_trace) (void)hipFree(p->d_trace);
     if (p->d_spec) (void)hipFree(p->d_spec);
     if (p->d_filt) (void)hipFree(p->d_filt);
@@ -355,15 +358,31 @@ int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_vali
             if (comb) tr = comb;
         }
         if (!any_slot) continue;
+        // transforms: rocFFT, except for non-power-of-two lengths of the form 2^a 3^b 5^c that
+        // fit in LDS, where rocFFT takes a multi-kernel path and the LDS transform is faster
+        if (!p->ldsfft_tried) {
+            p->ldsfft_tried = true;
+            const int Mh = N / 2;
+            if ((Mh & (Mh - 1)) != 0) {
+                const int r = ofx_ldsfft_create(Mh, p->device, &p->ldsfft);
+                if (r != OFX_OK && r != OFX_ERR_UNSUPPORTED) return r;
+            }
+        }
         OfxFftPlans* f = nullptr;
-        int rc = get_fft(p, nb, st, &f);
+        int rc = p->ldsfft ? OFX_OK : get_fft(p, nb, st, &f);
         if (rc) return rc;
         void* in1[1] = {(void*)tr};
         void* out1[1] = {(void*)p->d_spec};
         size_t tix = 0;
         rc = ofx_time_begin(p, st, &tix);
         if (rc) return rc;
-        OFX_FFT(rocfft_execute(f->r2c, in1, out1, f->info_r2c));
+        if (p->ldsfft) {
+            rc = ofx_ldsfft_exec(p->ldsfft, true, reinterpret_cast<const float2*>(tr), p->d_spec,
+                                 nb, st);
+            if (rc) return rc;
+        } else {
+            OFX_FFT(rocfft_execute(f->r2c, in1, out1, f->info_r2c));
+        }
         bool bands_done = p->bands.empty();
         bool any_search = false;
         for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
@@ -377,9 +396,15 @@ int ofx_rocfft_process(ofx_plan* p, const float* d_traces, const uint8_t* d_vali
                 hipLaunchKernelGGL(k_bands, dim3(nb), dim3(RB), 0, st, pd, p->d_vlow, cap, vld, out);
                 bands_done = true;
             }
-            void* in2[1] = {(void*)p->d_filt};
-            void* out2[1] = {(void*)p->d_amp};
-            OFX_FFT(rocfft_execute(f->c2r, in2, out2, f->info_c2r));
+            if (p->ldsfft) {
+                rc = ofx_ldsfft_exec(p->ldsfft, false, p->d_filt,
+                                     reinterpret_cast<float2*>(p->d_amp), nb, st);
+                if (rc) return rc;
+            } else {
+                void* in2[1] = {(void*)p->d_filt};
+                void* out2[1] = {(void*)p->d_amp};
+                OFX_FFT(rocfft_execute(f->c2r, in2, out2, f->info_c2r));
+            }
             hipLaunchKernelGGL(k_search, dim3(nb), dim3(RB), 0, st, pd, sd, p->d_amp,
                                p->d_vlow, cap, p->d_chi0, vld, out);
         }
