@@ -73,6 +73,17 @@ def cpu_baseline(seconds_target=12.0):
                       f"oracle/of1x1.py (fp64 NumPy FFTs, 1 thread), {el:.1f} s"}
 
 
+def metric_name():
+    """BASELINE.json's metric string (the file travels with the repository)."""
+    fallback = ("traces/sec of1x1_unconstrained (32768-sample, 1ch) @1/2/4/8 GPU; "
+                "% HBM roofline")
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as fh:
+            return json.load(fh).get("metric", fallback)
+    except (OSError, ValueError):
+        return fallback
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,7 +177,7 @@ def main():
         traces_per_launch = B / launches_per_step
         ach = traces_per_launch * ALGO_BYTES_PER_TRACE / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
         rec = {
-            "metric": "traces/sec of1x1_unconstrained (32768-sample, 1ch)",
+            "metric": metric_name(),
             "value": value, "unit": "traces/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
