@@ -34,6 +34,7 @@ namespace {
 constexpr int LDS_MAX_FAC = 16;
 constexpr int LDS_VLOW = 1024;           // low bins of V kept in LDS (lowchi2 / psd_amp)
 constexpr size_t LDS_BUDGET = 160 * 1024;
+constexpr size_t LDS_FIXED_BYTES = LDS_VLOW * 8 + 32 * 4 + 32 * 16;   // besides data and twiddles
 
 struct LdsGeom {
     int M, N, nfac;
@@ -158,12 +159,16 @@ __device__ __forceinline__ void stage(cpx* z, const cpx* tw1, int M, int L,
     }
 }
 
-template <bool FWD>
+// SMALL: only radices <= 5 are compiled in (a kernel for lengths without factors 8 and 16
+// then needs far fewer registers and can run with 1024 threads)
+template <bool FWD, bool SMALL = false>
 __device__ __forceinline__ void stage_any(int r, cpx* z, const cpx* tw1, int M, int L,
                                           unsigned magic) {
-    if (r == 16) stage<16, FWD>(z, tw1, M, L, magic);
-    else if (r == 8) stage<8, FWD>(z, tw1, M, L, magic);
-    else if (r == 5) stage<5, FWD>(z, tw1, M, L, magic);
+    if constexpr (!SMALL) {
+        if (r == 16) { stage<16, FWD>(z, tw1, M, L, magic); return; }
+        if (r == 8) { stage<8, FWD>(z, tw1, M, L, magic); return; }
+    }
+    if (r == 5) stage<5, FWD>(z, tw1, M, L, magic);
     else if (r == 4) stage<4, FWD>(z, tw1, M, L, magic);
     else if (r == 3) stage<3, FWD>(z, tw1, M, L, magic);
     else stage<2, FWD>(z, tw1, M, L, magic);
@@ -188,7 +193,7 @@ static int pos_of(int k, const LdsGeom& g) {
 // the bins from their digit-reversed positions; inverse scatters the bins to those positions,
 // runs the DIT stages and writes the row.  Unnormalised, as rocFFT.  Used by the N x M engine
 // for trace lengths where rocFFT falls back to its multi-kernel path.
-template <int BT, bool FWD>
+template <int BT, bool FWD, bool SMALL = false>
 __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restrict__ stw,
                                                 const int* __restrict__ pos,
                                                 const float2* __restrict__ in,
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
         if constexpr (FWD) {
             int L = M;
             for (int i = 0; i < g.nfac; ++i) {
-                stage_any<true>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                stage_any<true, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
                 L /= g.fac[i];
                 __syncthreads();
             }
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
                 L /= g.fac[i];
             }
             for (int i = g.nfac - 1; i >= 0; --i) {
-                stage_any<false>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                stage_any<false, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
                 __syncthreads();
             }
         }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
     }
 }
 
-template <int BT, bool PF>
+template <int BT, bool PF, bool SMALL = false>
 __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsSlot* __restrict__ slots,
                                             int nslots, const float2* __restrict__ stw,
                                             const LdsPair* __restrict__ pairs,
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
     // Software-pipelined trace load (when a trace fits NPF values per thread): the next
     // trace is requested into registers before the searches of the current one, so its HBM
     // latency hides under them -- with one workgroup per CU nothing else would.
-    constexpr int NPF = PF ? 34 : 1;
+    constexpr int NPF = PF ? (BT >= 1024 ? 17 : 34) : 1;     // NPF BT >= 17408 values
     cpx pf[NPF];
     bool have_pf = false;
     const bool can_pf = PF && (M <= NPF * BT);
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
             if (si == 0) {
                 int L = M;
                 for (int i = 0; i < g.nfac; ++i) {
-                    stage_any<true>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                    stage_any<true, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
                     L /= g.fac[i];
                     __syncthreads();
                 }
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     L /= g.fac[i];
                 }
                 for (int i = g.nfac - 1; i >= 0; --i) {
-                    stage_any<false>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                    stage_any<false, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
                     __syncthreads();
                 }
             }
@@ -547,12 +552,42 @@ size_t lds_bytes_for(int M, const std::vector<int>& fac) {
            32 * 4 + 32 * sizeof(OfxCand);
 }
 
+// radices 4, 2, 5, 3 only: more stages, but butterflies small enough for 1024 threads
+bool factorize_small(int M, std::vector<int>* fac) {
+    fac->clear();
+    int rem = M;
+    while (rem % 4 == 0) { fac->push_back(4); rem /= 4; }
+    while (rem % 2 == 0) { fac->push_back(2); rem /= 2; }
+    while (rem % 5 == 0) { fac->push_back(5); rem /= 5; }
+    while (rem % 3 == 0) { fac->push_back(3); rem /= 3; }
+    return rem == 1 && (int)fac->size() <= LDS_MAX_FAC;
+}
+
+// Factors of a length-M transform in LDS.  When the data alone takes more than half of the LDS
+// (one workgroup per CU) and the length has no power-of-two part above 4^2 to lose much by it,
+// the small-radix factorisation is taken if its twiddle tables still fit: the kernels then run
+// with 1024 threads, whose sixteen waves hide the LDS latency of the stages.
+bool choose_factors(int M, size_t fixed_bytes, std::vector<int>* fac, bool* small) {
+    *small = false;
+    if ((size_t)M * 8 + fixed_bytes > 80 * 1024 && (M & (M - 1)) != 0) {
+        std::vector<int> fs;
+        if (factorize_small(M, &fs) &&
+            (size_t)M * 8 + fixed_bytes + (size_t)stage_twiddle_count(M, fs) * 8 <= LDS_BUDGET) {
+            *fac = fs;
+            *small = true;
+            return true;
+        }
+    }
+    return factorize(M, fac);
+}
+
 }  // namespace
 
 bool ofx_lds_supported(int n_samples) {
     if (n_samples < 16 || (n_samples % 2)) return false;
     std::vector<int> fac;
-    if (!factorize(n_samples / 2, &fac)) return false;
+    bool small = false;
+    if (!choose_factors(n_samples / 2, LDS_FIXED_BYTES, &fac, &small)) return false;
     return lds_bytes_for(n_samples / 2, fac) <= LDS_BUDGET;
 }
 
@@ -569,13 +604,13 @@ int ofx_lds_release(ofx_plan* p) {
     return OFX_OK;
 }
 
-template <int BT, bool PF>
+template <int BT, bool PF, bool SMALL = false>
 static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int nslots,
                       const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
                       hipStream_t st, size_t lds) {
     static size_t attr_done = 0;
     if (attr_done < lds) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT, PF>),
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT, PF, SMALL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
         attr_done = LDS_BUDGET;
     }
@@ -599,7 +634,7 @@ static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int n
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_lds<BT, PF>), dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
+    hipLaunchKernelGGL((k_lds<BT, PF, SMALL>), dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
                        reinterpret_cast<const LdsSlot*>(p->d_lds_slots), nslots,
                        reinterpret_cast<const float2*>(p->d_lds_tw),
                        reinterpret_cast<const LdsPair*>(p->d_lds_pos), d_traces, d_valid, n, d_out,
@@ -614,7 +649,9 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
                     float* d_out, hipStream_t st) {
     const int N = p->N, M = N / 2;
     std::vector<int> fac;
-    if (!factorize(M, &fac) || lds_bytes_for(M, fac) > LDS_BUDGET) {
+    bool small_radix = false;
+    if (!choose_factors(M, LDS_FIXED_BYTES, &fac, &small_radix) ||
+        lds_bytes_for(M, fac) > LDS_BUDGET) {
         ofx_set_error("LDS engine: n_samples=%d is not supported", N);
         return OFX_ERR_UNSUPPORTED;
     }
@@ -738,6 +775,11 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     // the register prefetch of the next trace pays when only one workgroup fits a CU
     // (nothing else hides the HBM latency); with many small workgroups it only costs occupancy
     const bool pf = lds > 80 * 1024;
+    // one workgroup per CU and no radix-8 / 16 stage (e.g. 25000 samples = 4 * 5^5 points): the
+    // small butterflies fit 1024 threads, and sixteen waves hide the LDS latency of the stages
+    // (no register prefetch: 99 VGPRs, nothing spilled)
+    if (pf && small_radix)
+        return launch_lds<1024, false, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
     if (bf >= 1024 || pf)        // one workgroup per CU: give it eight waves
         return pf ? launch_lds<512, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds)
                   : launch_lds<512, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
@@ -758,11 +800,11 @@ struct OfxLdsFft {
 };
 
 namespace {
-template <int BT, bool FWD>
+template <int BT, bool FWD, bool SMALL = false>
 int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_fft<BT, FWD>),
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_fft<BT, FWD, SMALL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
         attr_done = true;
     }
@@ -771,7 +813,7 @@ int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, 
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)f->cu_count * per_cu;
     if (grid > rows) grid = rows;
-    hipLaunchKernelGGL((k_lds_fft<BT, FWD>), dim3((unsigned)grid), dim3(BT), f->lds, st, f->g,
+    hipLaunchKernelGGL((k_lds_fft<BT, FWD, SMALL>), dim3((unsigned)grid), dim3(BT), f->lds, st, f->g,
                        f->d_tw, f->d_pos, in, out, rows);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
@@ -781,7 +823,8 @@ int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, 
 int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
     std::vector<int> fac;
     const int M = n_complex;
-    if (M < 8 || !factorize(M, &fac)) return OFX_ERR_UNSUPPORTED;
+    bool small = false;
+    if (M < 8 || !choose_factors(M, 0, &fac, &small)) return OFX_ERR_UNSUPPORTED;
     const size_t lds = (size_t)M * 8 + (size_t)stage_twiddle_count(M, fac) * 8;
     if (lds > LDS_BUDGET) return OFX_ERR_UNSUPPORTED;
     OfxLdsFft* f = new OfxLdsFft();
@@ -839,6 +882,11 @@ int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, l
                     hipStream_t st) {
     if (rows <= 0) return OFX_OK;
     const bool big = f->g.M >= 1024;
+    bool small_radix = true;
+    for (int i = 0; i < f->g.nfac; ++i) small_radix = small_radix && f->g.fac[i] <= 5;
+    if (small_radix && f->g.M >= 8192)        // 16 waves per CU hide the LDS latency of the stages
+        return forward ? launch_lds_fft<1024, true, true>(f, in, out, rows, st)
+                       : launch_lds_fft<1024, false, true>(f, in, out, rows, st);
     if (forward)
         return big ? launch_lds_fft<512, true>(f, in, out, rows, st)
                    : launch_lds_fft<256, true>(f, in, out, rows, st);
