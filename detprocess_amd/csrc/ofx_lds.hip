@@ -159,13 +159,15 @@ __device__ __forceinline__ void stage(cpx* z, const cpx* tw1, int M, int L,
     }
 }
 
-// SMALL: only radices <= 5 are compiled in (a kernel for lengths without factors 8 and 16
-// then needs far fewer registers and can run with 1024 threads)
-template <bool FWD, bool SMALL = false>
+// MAXR: only radices <= MAXR are compiled in (a kernel for lengths without a radix-16 stage,
+// or without radix 8 and 16, needs far fewer registers and can run with 1024 threads)
+template <bool FWD, int MAXR = 16>
 __device__ __forceinline__ void stage_any(int r, cpx* z, const cpx* tw1, int M, int L,
                                           unsigned magic) {
-    if constexpr (!SMALL) {
+    if constexpr (MAXR >= 16) {
         if (r == 16) { stage<16, FWD>(z, tw1, M, L, magic); return; }
+    }
+    if constexpr (MAXR >= 8) {
         if (r == 8) { stage<8, FWD>(z, tw1, M, L, magic); return; }
     }
     if (r == 5) stage<5, FWD>(z, tw1, M, L, magic);
@@ -193,7 +195,7 @@ static int pos_of(int k, const LdsGeom& g) {
 // the bins from their digit-reversed positions; inverse scatters the bins to those positions,
 // runs the DIT stages and writes the row.  Unnormalised, as rocFFT.  Used by the N x M engine
 // for trace lengths where rocFFT falls back to its multi-kernel path.
-template <int BT, bool FWD, bool SMALL = false>
+template <int BT, bool FWD, int MAXR = 16>
 __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restrict__ stw,
                                                 const int* __restrict__ pos,
                                                 const float2* __restrict__ in,
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
         if constexpr (FWD) {
             int L = M;
             for (int i = 0; i < g.nfac; ++i) {
-                stage_any<true, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                stage_any<true, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
                 L /= g.fac[i];
                 __syncthreads();
             }
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
                 L /= g.fac[i];
             }
             for (int i = g.nfac - 1; i >= 0; --i) {
-                stage_any<false, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                stage_any<false, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
                 __syncthreads();
             }
         }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
     }
 }
 
-template <int BT, bool PF, bool SMALL = false>
+template <int BT, bool PF, int MAXR = 16>
 __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsSlot* __restrict__ slots,
                                             int nslots, const float2* __restrict__ stw,
                                             const LdsPair* __restrict__ pairs,
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
             if (si == 0) {
                 int L = M;
                 for (int i = 0; i < g.nfac; ++i) {
-                    stage_any<true, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                    stage_any<true, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
                     L /= g.fac[i];
                     __syncthreads();
                 }
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     L /= g.fac[i];
                 }
                 for (int i = g.nfac - 1; i >= 0; --i) {
-                    stage_any<false, SMALL>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                    stage_any<false, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
                     __syncthreads();
                 }
             }
@@ -552,10 +554,11 @@ size_t lds_bytes_for(int M, const std::vector<int>& fac) {
            32 * 4 + 32 * sizeof(OfxCand);
 }
 
-// radices 4, 2, 5, 3 only: more stages, but butterflies small enough for 1024 threads
+// no radix-16 stage: at most one more stage, but butterflies small enough for 1024 threads
 bool factorize_small(int M, std::vector<int>* fac) {
     fac->clear();
     int rem = M;
+    while (rem % 8 == 0) { fac->push_back(8); rem /= 8; }
     while (rem % 4 == 0) { fac->push_back(4); rem /= 4; }
     while (rem % 2 == 0) { fac->push_back(2); rem /= 2; }
     while (rem % 5 == 0) { fac->push_back(5); rem /= 5; }
@@ -564,9 +567,9 @@ bool factorize_small(int M, std::vector<int>* fac) {
 }
 
 // Factors of a length-M transform in LDS.  When the data alone takes more than half of the LDS
-// (one workgroup per CU) and the length has no power-of-two part above 4^2 to lose much by it,
-// the small-radix factorisation is taken if its twiddle tables still fit: the kernels then run
-// with 1024 threads, whose sixteen waves hide the LDS latency of the stages.
+// (one workgroup per CU) and the length is not a power of two, the factorisation without a
+// radix-16 stage is taken if its twiddle tables still fit: the kernels then run with 1024
+// threads, whose sixteen waves hide the LDS latency of the stages.
 bool choose_factors(int M, size_t fixed_bytes, std::vector<int>* fac, bool* small) {
     *small = false;
     if ((size_t)M * 8 + fixed_bytes > 80 * 1024 && (M & (M - 1)) != 0) {
@@ -604,13 +607,13 @@ int ofx_lds_release(ofx_plan* p) {
     return OFX_OK;
 }
 
-template <int BT, bool PF, bool SMALL = false>
+template <int BT, bool PF, int MAXR = 16>
 static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int nslots,
                       const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
                       hipStream_t st, size_t lds) {
     static size_t attr_done = 0;
     if (attr_done < lds) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT, PF, SMALL>),
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT, PF, MAXR>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
         attr_done = LDS_BUDGET;
     }
@@ -634,7 +637,7 @@ static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int n
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_lds<BT, PF, SMALL>), dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
+    hipLaunchKernelGGL((k_lds<BT, PF, MAXR>), dim3((unsigned)grid), dim3(BT), lds, st, pd, g,
                        reinterpret_cast<const LdsSlot*>(p->d_lds_slots), nslots,
                        reinterpret_cast<const float2*>(p->d_lds_tw),
                        reinterpret_cast<const LdsPair*>(p->d_lds_pos), d_traces, d_valid, n, d_out,
@@ -778,8 +781,12 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     // one workgroup per CU and no radix-8 / 16 stage (e.g. 25000 samples = 4 * 5^5 points): the
     // small butterflies fit 1024 threads, and sixteen waves hide the LDS latency of the stages
     // (no register prefetch: 99 VGPRs, nothing spilled)
-    if (pf && small_radix)
-        return launch_lds<1024, false, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+    int max_r = 2;
+    for (int r : fac) max_r = std::max(max_r, r);
+    if (pf && max_r <= 5)
+        return launch_lds<1024, false, 5>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+    if (pf && max_r <= 8)
+        return launch_lds<1024, false, 8>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
     if (bf >= 1024 || pf)        // one workgroup per CU: give it eight waves
         return pf ? launch_lds<512, true>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds)
                   : launch_lds<512, false>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
@@ -800,11 +807,11 @@ struct OfxLdsFft {
 };
 
 namespace {
-template <int BT, bool FWD, bool SMALL = false>
+template <int BT, bool FWD, int MAXR = 16>
 int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_fft<BT, FWD, SMALL>),
+        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_fft<BT, FWD, MAXR>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
         attr_done = true;
     }
@@ -813,7 +820,7 @@ int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, 
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)f->cu_count * per_cu;
     if (grid > rows) grid = rows;
-    hipLaunchKernelGGL((k_lds_fft<BT, FWD, SMALL>), dim3((unsigned)grid), dim3(BT), f->lds, st, f->g,
+    hipLaunchKernelGGL((k_lds_fft<BT, FWD, MAXR>), dim3((unsigned)grid), dim3(BT), f->lds, st, f->g,
                        f->d_tw, f->d_pos, in, out, rows);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
@@ -882,11 +889,14 @@ int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, l
                     hipStream_t st) {
     if (rows <= 0) return OFX_OK;
     const bool big = f->g.M >= 1024;
-    bool small_radix = true;
-    for (int i = 0; i < f->g.nfac; ++i) small_radix = small_radix && f->g.fac[i] <= 5;
-    if (small_radix && f->g.M >= 8192)        // 16 waves per CU hide the LDS latency of the stages
-        return forward ? launch_lds_fft<1024, true, true>(f, in, out, rows, st)
-                       : launch_lds_fft<1024, false, true>(f, in, out, rows, st);
+    int max_r = 2;
+    for (int i = 0; i < f->g.nfac; ++i) max_r = std::max(max_r, f->g.fac[i]);
+    if (max_r <= 5 && f->g.M >= 8192)         // 16 waves per CU hide the LDS latency of the stages
+        return forward ? launch_lds_fft<1024, true, 5>(f, in, out, rows, st)
+                       : launch_lds_fft<1024, false, 5>(f, in, out, rows, st);
+    if (max_r <= 8 && f->g.M >= 8192)
+        return forward ? launch_lds_fft<1024, true, 8>(f, in, out, rows, st)
+                       : launch_lds_fft<1024, false, 8>(f, in, out, rows, st);
     if (forward)
         return big ? launch_lds_fft<512, true>(f, in, out, rows, st)
                    : launch_lds_fft<256, true>(f, in, out, rows, st);
