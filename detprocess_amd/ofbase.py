@@ -315,7 +315,7 @@ class OFBase:
         key = (channel, template_tag)
         plan = self._nxm_plans.get(key)
         if plan is None:
-            plan = self._nxm_plans[key] = NxMPlan(tab, max_batch=min(self._max_batch, 2048),
+            plan = self._nxm_plans[key] = NxMPlan(tab, max_batch=min(self._max_batch, 4096),
                                                   device=self._device)
         if channel in self._signals:                      # stored as one [B, C, N] block
             ev = self._signals[channel]

@@ -90,7 +90,7 @@ def nxm_search_range(n_samples, n_pretrigger, fs, window_min_from_trig_usec=None
 class NxMPlan:
     """Handle on an ``ofx_nxm`` object (include/ofx.h)."""
 
-    def __init__(self, tables: NxMTables, max_batch=2048, device=0):
+    def __init__(self, tables: NxMTables, max_batch=4096, device=0):
         self._lib = _lib.load()
         self._h = C.c_void_p()
         self.tables = tables

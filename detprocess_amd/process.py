@@ -384,7 +384,7 @@ class FeatureProcessing:
                 raise ValueError("ERROR: template pretrigger differs from the trace pretrigger")
             tables = build_nxm_filter(template, csd, self._fs, pre_t, coupling,
                                       list(peaks) if peaks else None, harm)
-            plan = NxMPlan(tables, max_batch=min(self._max_batch, 2048), device=self._device)
+            plan = NxMPlan(tables, max_batch=min(self._max_batch, 4096), device=self._device)
             plan.set_channels(len(self._channels), idx)
             cp = _ChannelPlan()
             cp.nxm = True

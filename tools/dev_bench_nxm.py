@@ -8,7 +8,7 @@ FS = 1.25e6
 def run(n, C, M, B, unconstrained=False):
     pre = n // 2
     t = make_templates(n, pre, C, M); csd = make_csd(n, C)
-    plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=2048)
+    plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=int(sys.argv[1]) if len(sys.argv) > 1 else 2048)
     plan.add_search('nodelay')
     lo, hi = nxm_search_range(n, pre, FS, -100, 100)
     plan.add_search('delay', *( (0, n) if unconstrained else (lo, hi)))
