@@ -19,6 +19,8 @@
 #include <vector>
 
 #include "ofx_common.h"
+#include <cstdlib>
+
 #include "ofx_device.h"
 #include "ofx_fft_regs.h"
 
@@ -371,8 +373,10 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     L /= g.fac[i];
                     __syncthreads();
                 }
-                if (pass_n > 1)
+                if (pass_n > 1) {
                     for (int m = tid; m < M; m += BT) myspec[m] = make_float2(z[m].x, z[m].y);
+                    __syncthreads();       // the middle step rewrites z in place, at other threads' m
+                }
             } else {
                 __syncthreads();
             }
@@ -567,12 +571,15 @@ bool factorize_small(int M, std::vector<int>* fac) {
 }
 
 // Factors of a length-M transform in LDS.  When the data alone takes more than half of the LDS
-// (one workgroup per CU) and the length is not a power of two, the factorisation without a
-// radix-16 stage is taken if its twiddle tables still fit: the kernels then run with 1024
+// (one workgroup per CU), the factorisation without a radix-16 stage is taken if its twiddle
+// tables still fit: the kernels then run with 1024
 // threads, whose sixteen waves hide the LDS latency of the stages.
 bool choose_factors(int M, size_t fixed_bytes, std::vector<int>* fac, bool* small) {
     *small = false;
-    if ((size_t)M * 8 + fixed_bytes > 80 * 1024 && (M & (M - 1)) != 0) {
+    const char* dg = getenv("OFX_DIAG_LDS_SMALL");
+    // measured on MI355X: also pays for powers of two in that regime (32768 samples: 4.6 -> 5.3 M
+    // traces/s) and at 8192 samples (8^4 points: 19.3 -> 21.9 M); not at 4096 or 16384 samples
+    if ((dg && dg[0] == '1') || (size_t)M * 8 + fixed_bytes > 80 * 1024 || M == 4096) {
         std::vector<int> fs;
         if (factorize_small(M, &fs) &&
             (size_t)M * 8 + fixed_bytes + (size_t)stage_twiddle_count(M, fs) * 8 <= LDS_BUDGET) {
@@ -783,6 +790,14 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     // (no register prefetch: 99 VGPRs, nothing spilled)
     int max_r = 2;
     for (int r : fac) max_r = std::max(max_r, r);
+    if (const char* bt = getenv("OFX_DIAG_LDS_BT")) {
+        if (max_r <= 8) {
+            const int v = atoi(bt);
+            if (v == 1024) return launch_lds<1024, false, 8>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+            if (v == 512) return launch_lds<512, false, 8>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+            if (v == 256) return launch_lds<256, false, 8>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
+        }
+    }
     if (pf && max_r <= 5)
         return launch_lds<1024, false, 5>(p, pd, g, nslots, d_traces, d_valid, n, d_out, st, lds);
     if (pf && max_r <= 8)
