@@ -478,3 +478,41 @@ def test_coloured_noise_generator_matches_its_psd():
     r = plan2.process(z)
     assert float(((r[:, 7] - pre - tr[:, 1]).abs() <= 3).float().mean()) > 0.99
     assert float((((r[:, 0] - tr[:, 0]) / ft.ampres).abs() < 5).float().mean()) > 0.995
+
+
+@pytest.mark.parametrize("n", [24000, 25000, 30000])
+def test_lds_three_slots_at_other_lengths(n):
+    """Several template tags on the LDS engine at lengths that run its 1024-thread builds
+    (radix <= 8 and radix <= 5): every slot equals the oracle and a single-slot plan.  Guards
+    the barrier between parking the spectrum and the in-place middle step."""
+    from detprocess_amd import OFPlan
+    pre = n // 2
+    psd = synth.make_psd(n, FS)
+    kinds = ("pulse", "glitch", "muon")
+    tmpls = [synth.make_template(n, pre, FS, k) for k in kinds]
+    fts = [build_filter(t, psd, FS, pre) for t in tmpls]
+    filts = [orc.OFFilter(t, psd, FS, pre) for t in tmpls]
+    plan = OFPlan(n, pre, FS, max_batch=64, device=0, engine="lds")
+    ids = []
+    for s, ft in enumerate(fts):
+        plan.set_filter(s, ft)
+        ids.append((plan.add_search(s, "nodelay"), plan.add_search(s, "delay")))
+    x, _, _ = synth.make_traces(600, tmpls[0], psd, FS, fts[0].ampres, seed=n)
+    x32 = x.astype(np.float32)
+    out = _run(plan, x32)                      # more events than workgroups: every CU is busy
+    x64 = x32[:16].astype(np.float64)
+    for s, (ft, filt) in enumerate(zip(fts, filts)):
+        check_search(out[:16], plan.search_offset(s, ids[s][0]),
+                     orc.process_events(filt, x64, "nodelay"), "", ft.ampres, FS, f"{kinds[s]}/nodelay")
+        check_search(out[:16], plan.search_offset(s, ids[s][1]),
+                     orc.process_events(filt, x64, "unconstrained"), "", ft.ampres, FS, f"{kinds[s]}/delay")
+        solo = OFPlan(n, pre, FS, max_batch=64, device=0, engine="lds")
+        solo.set_filter(0, ft)
+        a = solo.add_search(0, "nodelay")
+        b = solo.add_search(0, "delay")
+        so = _run(solo, x32)
+        for mine, theirs in ((ids[s][0], a), (ids[s][1], b)):
+            o1, o2 = plan.search_offset(s, mine), solo.search_offset(0, theirs)
+            assert np.array_equal(out[:, o1:o1 + 8], so[:, o2:o2 + 8]), (kinds[s], n)
+        solo.close()
+    plan.close()
