@@ -398,7 +398,7 @@ def test_full_size_properties():
                  "", ft.ampres, FS, "full-size sample")
 
 
-@pytest.mark.parametrize("n", [25000, 4096])
+@pytest.mark.parametrize("n", [25000, 30000, 8192, 4096])
 def test_lds_engine_properties_at_scale(n):
     """The LDS engine on a large device-generated batch of the reference example's trace
     length (and a short power of two): bin-for-bin agreement with the independent ROCFFT
