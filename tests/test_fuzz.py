@@ -1,0 +1,17 @@
+"""A fixed slice of the randomised engine-vs-oracle cross-check (tools/fuzz_engines.py): random
+trace lengths (also odd half-lengths and the 1024-thread LDS builds), pretrigger positions, batch
+sizes, windows, outside-window and interpolated fits, one to three template tags, every engine
+that accepts the case."""
+import importlib.util
+import os
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_random_configurations_match_the_oracle():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "fuzz_engines.py")
+    spec = importlib.util.spec_from_file_location("fuzz_engines", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(16, 2026, verbose=False) == 0
