@@ -1,7 +1,8 @@
 """A fixed slice of the randomised engine-vs-oracle cross-check (tools/fuzz_engines.py): random
 trace lengths (also odd half-lengths and the 1024-thread LDS builds), pretrigger positions, batch
 sizes, windows, outside-window and interpolated fits, one to three template tags, every engine
-that accepts the case."""
+that accepts the case; and of the N x M engine (channel / template counts, channel maps, valid
+masks, windows, every transform build)."""
 import importlib.util
 import os
 
@@ -15,3 +16,4 @@ def test_random_configurations_match_the_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(16, 2026, verbose=False) == 0
+    assert mod.run_nxm(16, 2026, verbose=False) == 0

@@ -71,7 +71,67 @@ def run(cases, seed, verbose=True):
   return bad
 
 
+def run_nxm(cases, seed, verbose=True):
+    """N x M engine: random lengths (rocFFT and every LDS-transform build), channel / template
+    counts, channel maps, valid masks, windows."""
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter
+    from oracle import ofnxm as onm
+    import test_ofnxm as T
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        n = int(rng.choice([2 * int(rng.integers(64, 1500)), int(rng.choice([250, 1000, 1024, 2000, 4096, 5000, 6250, 8192,
+                                                                             12000, 16384, 20000, 25000, 30000]))]))
+        pre = int(rng.integers(n // 8, n - n // 8))
+        C, M = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        B = int(rng.integers(1, 40)) if n <= 8192 else int(rng.integers(1, 7))
+        tm = T.make_templates(n, pre, C, M)
+        csd = T.make_csd(n, C)
+        filt = onm.NxMFilter(tm, csd, FS, pre)
+        if np.linalg.cond(filt.P) > 50.0:      # near-degenerate template sets amplify fp32 rounding
+            continue                           # beyond the stated tolerance (not an engine property)
+        ev, _, _ = T.make_events(B, tm, csd, filt.ampres, seed=int(rng.integers(1 << 30)), max_delay=max(1, n // 16))
+        n_total = int(rng.integers(C, C + 3))
+        idx = rng.permutation(n_total)[:C]
+        full = rng.normal(0, 1e-7, (B, n_total, n)).astype(np.float32)
+        full[:, idx] = ev.astype(np.float32)
+        valid = (rng.random(B) < 0.85).astype(np.uint8)
+        lo = int(rng.integers(0, n - 2)); hi = int(rng.integers(lo + 1, n + 1))
+        outside = bool(rng.integers(0, 2))
+        tag = f'nxm case {c} N={n} pre={pre} {C}x{M} B={B} map={list(idx)}/{n_total} win=[{lo},{hi}) out={outside}'
+        plan = NxMPlan(build_nxm_filter(tm, csd, FS, pre), max_batch=int(rng.choice([3, 8, 64])))
+        try:
+            plan.set_channels(n_total, idx)
+            s0 = plan.add_search('nodelay'); s1 = plan.add_search('delay'); s2 = plan.add_search('delay', lo, hi, outside)
+            out = plan.process(torch.as_tensor(full, device='cuda'), torch.as_tensor(valid, device='cuda')).cpu().numpy()
+            ok = valid.astype(bool)
+            assert np.all(out[~ok] == -999999.0), tag + ' sentinel rows'
+            if ok.any():
+                x = full[ok][:, idx].astype(np.float64)
+                r = onm.process_events(filt, x)
+                T._check(plan, out[ok], s0, r, filt, nodelay=True)
+                T._check(plan, out[ok], s1, r, filt)
+                rw = onm.process_events(filt, x, window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)
+                if np.all(rw['index'] >= 0):
+                    T._check(plan, out[ok], s2, rw, filt)
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH', tag, str(e)[:200], flush=True)
+        except Exception:
+            bad += 1
+            print('ERROR', tag); traceback.print_exc()
+        finally:
+            plan.close()
+        if verbose:
+            print(tag, 'done', flush=True)
+    return bad
+
+
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    bad = run(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    if len(sys.argv) > 3 and sys.argv[3] == 'nxm':
+        bad = run_nxm(cases, seed)
+    else:
+        bad = run(cases, seed)
     print('fuzz finished:', cases, 'cases,', bad, 'problems')
