@@ -2,7 +2,8 @@
 trace lengths (also odd half-lengths and the 1024-thread LDS builds), pretrigger positions, batch
 sizes, windows, outside-window and interpolated fits, one to three template tags, every engine
 that accepts the case; and of the N x M engine (channel / template counts, channel maps, valid
-masks, windows, every transform build)."""
+masks, windows, every transform build) and of the trigger stage (filter and stream lengths around
+the overlap-save block boundaries, 1 x 1 and N x M, padding on and off)."""
 import importlib.util
 import os
 
@@ -17,3 +18,4 @@ def test_random_configurations_match_the_oracle():
     spec.loader.exec_module(mod)
     assert mod.run(16, 2026, verbose=False) == 0
     assert mod.run_nxm(16, 2026, verbose=False) == 0
+    assert mod.run_trigger(24, 2026, verbose=False) == 0

@@ -127,11 +127,77 @@ def run_nxm(cases, seed, verbose=True):
     return bad
 
 
+def run_trigger(cases, seed, verbose=True):
+    """Trigger stage: random filter lengths, stream lengths around the
+    overlap-save block boundaries, channel / amplitude counts, padding on and off."""
+    from detprocess_amd import OptimumFilterTrigger
+    from oracle import oftrigger as ot
+    import test_ofnxm as T
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        nxm = bool(rng.integers(0, 2))
+        n = 2 * int(rng.integers(32, 1500))              # even: odd trace lengths are rejected
+        pre = int(rng.integers(n // 8, n - n // 8))
+        P = 4096
+        while P < 4 * n:
+            P *= 2
+        H = P - (n - 1)
+        kblk = int(rng.integers(1, 6))
+        L = int(max(n + 2, kblk * H + int(rng.integers(-3, 4)) - int(rng.choice([0, (n - 1) // 2, n - 1]))))
+        padding = bool(rng.integers(0, 2))
+        C, M = (int(rng.integers(1, 4)), int(rng.integers(1, 4))) if nxm else (1, 1)
+        tag = f'trigger case {c} N={n} pre={pre} L={L} {C}x{M} padding={padding}'
+        try:
+            if nxm:
+                tm = T.make_templates(n, pre, C, M)
+                csd = T.make_csd(n, C)
+                tr = ot.OFTriggerNxM(FS, tm, csd, pre)
+                if np.linalg.cond(tr.w_matrix) > 50.0:
+                    continue
+                x = np.zeros((C, L))
+                for a in range(C):
+                    x[a] = synth.coloured_noise(rng, L // n + 2, csd[a, a].real, FS).reshape(-1)[:L]
+                for p0 in rng.integers(0, max(1, L - n), 3):
+                    x[:, p0:p0 + n] += np.einsum('m,amn->an', tr.resolution * rng.uniform(5, 50, M), tm)[:, :L - p0]
+                g = OptimumFilterTrigger(list('abc'[:C]), FS, tm, csd, pre)
+            else:
+                tmpl = synth.make_template(n, pre, FS)
+                psd = synth.make_psd(n, FS)
+                tr = ot.OFTrigger(FS, tmpl, psd, pre)
+                x = synth.coloured_noise(rng, L // n + 2, psd, FS).reshape(-1)[:L]
+                for p0 in rng.integers(0, max(1, L - n), 3):
+                    x[p0:p0 + n] += (tr.resolution * rng.uniform(5, 50) * tmpl)[:L - p0]
+                g = OptimumFilterTrigger('a', FS, tmpl, psd, pre)
+            x32 = x.astype(np.float32)
+            filt, dchi = tr.update_trace(x32.astype(np.float64), padding=padding)
+            g.update_trace(x32, padding=padding)
+            gf = g.get_filtered_trace().astype(np.float64)
+            gd = g.get_filtered_delta_chi2().astype(np.float64)
+            filt = np.atleast_2d(filt)
+            scale = np.max(np.abs(filt), axis=1, keepdims=True) + 1e-300
+            assert gf.shape == filt.shape, tag + f' shape {gf.shape} vs {filt.shape}'
+            assert np.all(np.abs(gf - filt) <= 4e-5 * scale), tag + f' filtered {np.max(np.abs(gf - filt) / scale):.2e}'
+            assert np.max(np.abs(gd - dchi)) <= 8e-5 * max(np.max(dchi), 1e-300), tag + ' delta chi2'
+            g.close()
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH', str(e)[:200], flush=True)
+        except Exception:
+            bad += 1
+            print('ERROR', tag); traceback.print_exc()
+        if verbose:
+            print(tag, 'done', flush=True)
+    return bad
+
+
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     if len(sys.argv) > 3 and sys.argv[3] == 'nxm':
         bad = run_nxm(cases, seed)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'trigger':
+        bad = run_trigger(cases, seed)
     else:
         bad = run(cases, seed)
     print('fuzz finished:', cases, 'cases,', bad, 'problems')
