@@ -191,6 +191,57 @@ def run_trigger(cases, seed, verbose=True):
     return bad
 
 
+def run_adc(cases, seed, verbose=True):
+    """Raw-data front end: events cut on the GPU out of int16 streams (windows hanging over
+    either end included) equal the same windows cut and converted on the host, bit for bit."""
+    rng = np.random.default_rng(seed)
+    bad = 0
+    for c in range(cases):
+        n = 2 * int(rng.integers(64, 3000))
+        pre = int(rng.integers(1, n - 1))
+        C = int(rng.integers(1, 5))
+        n_stream = int(rng.integers(n, 12 * n))
+        B = int(rng.integers(1, 60))
+        tag = f'adc case {c} N={n} pre={pre} C={C} stream={n_stream} B={B}'
+        adc = rng.integers(-32768, 32768, (C, n_stream), dtype=np.int16)
+        trig = rng.integers(-n, n_stream + n, B).astype(np.int64)
+        trig[: min(B, 4)] = [pre, n_stream - (n - pre), pre - 1, n_stream - (n - pre) + 1][: min(B, 4)]
+        scale = rng.uniform(1e-12, 5e-12, C)
+        offset = rng.uniform(-1e-9, 1e-9, C)
+        tmpl = synth.make_template(n, pre, FS)
+        psd = synth.make_psd(n, FS)
+        plan = OFPlan(n, pre, FS, max_batch=int(rng.choice([5, 32])), engine=str(rng.choice(['auto', 'rocfft'])))
+        try:
+            plan.set_filter(0, build_filter(tmpl, psd, FS, pre))
+            plan.add_search(0, 'delay')
+            plan.add_tdwindow(0, n - 1)
+            ch = int(rng.integers(0, C))
+            plan.set_channels(C, [ch], [1.0])
+            got = plan.process_adc(adc, trig, scale, offset)
+            lo = trig - pre
+            ok = (lo >= 0) & (lo + n <= n_stream)
+            ev = np.zeros((B, C, n), dtype=np.float32)
+            for b in np.nonzero(ok)[0]:
+                for k in range(C):
+                    ev[b, k] = adc[k, lo[b]:lo[b] + n].astype(np.float32) * np.float32(scale[k]) + np.float32(offset[k])
+            want = plan.process(ev, valid=ok.astype(np.uint8))
+            assert np.array_equal(got, want), tag + f' differ in rows {np.nonzero(np.any(got != want, axis=1))[0][:5]}'
+            assert np.all(got[~ok] == -999999.0), tag + ' sentinel'
+            dev = plan.process_adc(torch.as_tensor(adc, device='cuda'), trig, scale, offset)
+            assert np.array_equal(dev.cpu().numpy(), want), tag + ' device-resident stream'
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH', str(e)[:200], flush=True)
+        except Exception:
+            bad += 1
+            print('ERROR', tag); traceback.print_exc()
+        finally:
+            plan.close()
+        if verbose:
+            print(tag, 'done', flush=True)
+    return bad
+
+
 if __name__ == '__main__':
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -198,6 +249,8 @@ if __name__ == '__main__':
         bad = run_nxm(cases, seed)
     elif len(sys.argv) > 3 and sys.argv[3] == 'trigger':
         bad = run_trigger(cases, seed)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'adc':
+        bad = run_adc(cases, seed)
     else:
         bad = run(cases, seed)
     print('fuzz finished:', cases, 'cases,', bad, 'problems')
