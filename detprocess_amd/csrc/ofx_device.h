@@ -186,7 +186,8 @@ __device__ __forceinline__ float ofx_lowchi2_term(int k, int N, int d, float amp
 // interpolate=True: vertex of the parabola through chi2 at the rolled bins idx-1, idx,
 // idx+1 (chi2 = chi0 - A^2 norm) and the amplitude parabola evaluated at the same
 // offset (oracle/of1x1.py interpolate_of).  am / a0 / ap: amplitudes at idx-1 / idx /
-// idx+1.  No refinement at the array ends or when the three points are not convex.
+// idx+1.  No refinement at the array ends, when the three points are not convex, or when the
+// vertex lies more than one bin away (window edge with the true minimum outside).
 struct OfxRefined {
     float amp, frac, chi2;
 };
@@ -202,6 +203,7 @@ __device__ __forceinline__ OfxRefined ofx_interpolate(float am, float a0, float 
     const float den = (a0 - am) * (a0 + am) + (a0 - ap) * (a0 + ap);
     if (!(den * norm > 0.0f)) return r;
     const float x = 0.5f * dpm / den;
+    if (!(fabsf(x) <= 1.0f)) return r;      // vertex beyond the neighbours: an extrapolation
     r.frac = x;
     r.chi2 = r.chi2 - 0.125f * norm * dpm * dpm / den;
     r.amp = a0 + 0.5f * (ap - am) * x + 0.5f * ((am - a0) + (ap - a0)) * x * x;

@@ -220,7 +220,11 @@ def interpolate_of(amps_r, chi2_r, ind, dt):
 
     Unpinned (QETpy's helper unseen): vertex of the parabola through the three
     chi2 points; amplitude from the parabola through the three amplitudes at
-    the same offset.
+    the same offset.  No refinement at the array ends, when the three points are
+    not convex, or when the vertex lies more than one bin away (the discrete
+    minimum of a window can sit on its edge with the true minimum outside: the
+    parabola then extrapolates, by hundreds of bins in noise, to meaningless
+    amplitudes).
     """
     N = chi2_r.shape[0]
     if ind <= 0 or ind >= N - 1:
@@ -230,6 +234,8 @@ def interpolate_of(amps_r, chi2_r, ind, dt):
     if den <= 0.0:
         return amps_r[ind], 0.0, chi2_r[ind]
     x = 0.5 * (y0 - y2) / den
+    if abs(x) > 1.0:
+        return amps_r[ind], 0.0, chi2_r[ind]
     chi2 = y1 - 0.125 * (y0 - y2) ** 2 / den
     a0, a1, a2 = amps_r[ind - 1], amps_r[ind], amps_r[ind + 1]
     amp = a1 + 0.5 * (a2 - a0) * x + 0.5 * (a0 - 2.0 * a1 + a2) * x * x

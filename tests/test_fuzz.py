@@ -4,7 +4,9 @@ sizes, windows, outside-window and interpolated fits, one to three template tags
 that accepts the case; and of the N x M engine (channel / template counts, channel maps, valid
 masks, windows, every transform build) and of the trigger stage (filter and stream lengths around
 the overlap-save block boundaries, 1 x 1 and N x M, padding on and off) and of the raw-data front end (windows cut on the GPU out of
-int16 streams, also hanging over either end, against host-cut windows, bit for bit)."""
+int16 streams, also hanging over either end, against host-cut windows, bit for bit); and random
+plans on the FUSED kernel (template tags, fit kinds, time-domain windows, channel sums, masks,
+batches above the persistent grid) against the ROCFFT engine and the oracle."""
 import importlib.util
 import os
 
@@ -21,3 +23,4 @@ def test_random_configurations_match_the_oracle():
     assert mod.run_nxm(16, 2026, verbose=False) == 0
     assert mod.run_trigger(24, 2026, verbose=False) == 0
     assert mod.run_adc(10, 2026, verbose=False) == 0
+    assert mod.run_fused(6, 2026, verbose=False) == 0

@@ -191,6 +191,117 @@ def run_trigger(cases, seed, verbose=True):
     return bad
 
 
+def run_fused(cases, seed, verbose=True):
+    """The FUSED kernel at 32768 samples under random plans (1-3 template tags, no-delay /
+    full / windowed / outside / interpolated fits, 0-3 time-domain windows, channel sums with
+    weights, valid masks, batches below and above the persistent grid) against the ROCFFT
+    engine on every event and against the oracle on a few."""
+    rng = np.random.default_rng(seed)
+    n, bad = 32768, 0
+    psd = synth.make_psd(n, FS)
+    for c in range(cases):
+        pre = int(rng.choice([16384, 16384, int(rng.integers(4096, 28000))]))
+        kinds = ['pulse', 'glitch', 'muon'][: int(rng.integers(1, 4))]
+        tmpls = [synth.make_template(n, pre, FS, k) for k in kinds]
+        fts = [build_filter(t, psd, FS, pre) for t in tmpls]
+        filts = [orc.OFFilter(t, psd, FS, pre) for t in tmpls]
+        B = int(rng.choice([3, 70, 600, 1100]))
+        n_total = int(rng.integers(1, 4))
+        nterm = int(rng.integers(1, min(2, n_total) + 1))
+        chans = list(rng.permutation(n_total)[:nterm])
+        weights = [1.0] if (nterm == 1 and rng.integers(0, 2)) else list(rng.choice([1.0, -1.0, 0.7, 1.3], nterm))
+        x, _, _ = synth.make_traces(B * n_total, tmpls[0], psd, FS, fts[0].ampres, seed=int(rng.integers(1 << 30)),
+                                    max_delay=2000)
+        ev = x.reshape(B, n_total, n).astype(np.float32)
+        valid = (rng.random(B) < 0.9).astype(np.uint8)
+        searches = []
+        for s in range(len(kinds)):
+            ss = []
+            if rng.integers(0, 2): ss.append(('nodelay', 0, n, False, False))
+            if rng.integers(0, 2): ss.append(('delay', 0, n, False, bool(rng.integers(0, 2))))
+            if rng.integers(0, 2) or not ss:
+                lo = int(rng.integers(0, n - 2)); hi = int(rng.integers(lo + 1, min(n, lo + int(rng.choice([50, 1000, 20000]))) + 1))
+                ss.append(('delay', lo, hi, bool(rng.integers(0, 4) == 0), bool(rng.integers(0, 2))))
+            searches.append(ss)
+        tdw = []
+        for _ in range(int(rng.integers(0, 4))):
+            lo = int(rng.integers(0, n - 2)); tdw.append((lo, int(rng.integers(lo + 1, n))))
+        tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)}'
+        outs = {}
+        try:
+            for eng in ('fused', 'rocfft'):
+                plan = OFPlan(n, pre, FS, max_batch=int(rng.choice([64, 8192])), engine=eng)
+                ids = []
+                for s, ft in enumerate(fts):
+                    plan.set_filter(s, ft)
+                    ids.append([plan.add_search(s, k, lo, hi, outside, 10000.0, interp) for (k, lo, hi, outside, interp) in searches[s]])
+                wids = [plan.add_tdwindow(lo, hi) for lo, hi in tdw]
+                if n_total > 1 or nterm > 1 or weights[0] != 1.0:
+                    plan.set_channels(n_total, chans, weights)
+                inp = torch.as_tensor(ev if n_total > 1 or nterm > 1 or weights[0] != 1.0 else ev[:, 0], device='cuda')
+                outs[eng] = plan.process(inp, valid=torch.as_tensor(valid, device='cuda')).cpu().numpy().astype(np.float64)
+                offs = [[plan.search_offset(s, q) for q in ids[s]] for s in range(len(kinds))]
+                woffs = [plan.tdwindow_offset(w) for w in wids]
+                plan.close()
+            a, b = outs['fused'], outs['rocfft']
+            ok = valid.astype(bool)
+            assert np.all(a[~ok] == -999999.0) and np.all(b[~ok] == -999999.0), tag + ' sentinel rows'
+            comb = np.zeros((B, n))
+            for ch, w in zip(chans, weights):
+                comb += np.float32(w).astype(np.float64) * ev[:, ch].astype(np.float64)
+            for s in range(len(kinds)):
+                for q, (k, lo, hi, outside, interp) in enumerate(searches[s]):
+                    o = offs[s][q]
+                    flips = a[ok, o + 7] != b[ok, o + 7]
+                    assert flips.mean() <= 0.01, tag + f' slot {s} search {q}: {flips.sum()} bin flips'
+                    same = ~flips
+                    da = np.abs(a[ok][same, o] - b[ok][same, o])
+                    lim = 1e-4 * np.abs(b[ok][same, o]) + 2e-4 * fts[s].ampres
+                    if not np.all(da <= lim):
+                        w_ = int(np.argmax(da / lim))
+                        e_ = int(np.nonzero(ok)[0][same][w_])
+                        r_ = orc.process_events(filts[s], comb[e_:e_ + 1], 'nodelay' if k == 'nodelay' else 'constrained', 10000.0,
+                                                interpolate=interp, **({} if k == 'nodelay' else dict(
+                                                    window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
+                        r0_ = orc.process_events(filts[s], comb[e_:e_ + 1], 'nodelay' if k == 'nodelay' else 'constrained', 10000.0,
+                                                 interpolate=False, **({} if k == 'nodelay' else dict(
+                                                     window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
+                        print(f'   oracle amp {r_["amp"][0]:.4e} t0 {r_["t0"][0]:.6e} idx {r_["index"][0]} | no-interp amp {r0_["amp"][0]:.4e} | '
+                              f'fused t0 {a[e_, o + 1]:.6e} idx {a[e_, o + 7]} rocfft t0 {b[e_, o + 1]:.6e} idx {b[e_, o + 7]}', flush=True)
+                        raise AssertionError(tag + f' amp s{s} q{q} {searches[s][q]}: worst {np.max(da / lim):.1f}x at event '
+                                             f'{np.nonzero(ok)[0][same][w_]} a={a[ok][same, o][w_]:.4e} b={b[ok][same, o][w_]:.4e} '
+                                             f'sigma={fts[s].ampres:.3e}')
+                    assert np.allclose(a[ok][:, o + 2], b[ok][:, o + 2], rtol=2e-4), tag + f' chi2 s{s} q{q}'
+                    sel = np.nonzero(ok)[0][:4]
+                    mode = 'nodelay' if k == 'nodelay' else 'constrained'
+                    r = orc.process_events(filts[s], comb[sel], mode, 10000.0, interpolate=interp,
+                                           **({} if k == 'nodelay' else dict(window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
+                    if np.all(r['index'] >= 0):
+                        # the sub-sample offset of a noise peak is a ratio of amplitude differences far
+                        # below fp32 resolution: interpolated fits are checked on clear pulses only
+                        keep = np.abs(r['amp']) > 20 * fts[s].ampres if interp else np.ones(len(sel), bool)
+                        if keep.any():
+                            rk = {kk: np.asarray(v)[keep] for kk, v in r.items()}
+                            check_search(a[sel][keep], o, rk, '', fts[s].ampres, FS,
+                                         tag + f' oracle s{s} q{q} {searches[s][q]}', interpolated=interp)
+            for w, (lo, hi) in zip(woffs, tdw):
+                seg = comb[ok][:, lo:hi]
+                sc = np.abs(comb).max()
+                assert np.allclose(a[ok][:, w + 0], seg.mean(axis=1), rtol=1e-4, atol=3e-6 * sc), tag + ' baseline'
+                assert np.allclose(a[ok][:, w + 2], seg.max(axis=1), rtol=1e-6, atol=1e-6 * sc), tag + ' maximum'
+                assert np.allclose(a[ok][:, w + 3], seg.min(axis=1), rtol=1e-6, atol=1e-6 * sc), tag + ' minimum'
+                assert np.allclose(a[ok][:, w:w + 4], b[ok][:, w:w + 4], rtol=1e-4, atol=3e-6 * sc), tag + ' td vs rocfft'
+        except AssertionError as e:
+            bad += 1
+            print('MISMATCH', str(e)[:300], flush=True)
+        except Exception:
+            bad += 1
+            print('ERROR', tag); traceback.print_exc()
+        if verbose:
+            print(tag, 'done', flush=True)
+    return bad
+
+
 def run_adc(cases, seed, verbose=True):
     """Raw-data front end: events cut on the GPU out of int16 streams (windows hanging over
     either end included) equal the same windows cut and converted on the host, bit for bit."""
@@ -249,6 +360,8 @@ if __name__ == '__main__':
         bad = run_nxm(cases, seed)
     elif len(sys.argv) > 3 and sys.argv[3] == 'trigger':
         bad = run_trigger(cases, seed)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'fused':
+        bad = run_fused(cases, seed)
     elif len(sys.argv) > 3 and sys.argv[3] == 'adc':
         bad = run_adc(cases, seed)
     else:
