@@ -44,13 +44,30 @@ def run(cases, seed, verbose=True):
                   ids.append((plan.add_search(s, 'nodelay', lowchi2_fcutoff=fcut),
                               plan.add_search(s, 'delay', lowchi2_fcutoff=fcut, interpolate=interp),
                               plan.add_search(s, 'delay', lo, hi, outside, fcut)))
-              w = plan.add_tdwindow(min(lo, n - 2), max(min(hi, n - 1), min(lo, n - 2) + 1))
+              wlo, whi = min(lo, n - 2), max(min(hi, n - 1), min(lo, n - 2) + 1)
+              w = plan.add_tdwindow(wlo, whi)
+              klo = int(rng.integers(1, max(2, min(200, n // 4))))
+              khi = int(rng.integers(klo + 1, min(n // 2, klo + 300) + 1))
+              band = plan.add_band(klo, khi)
               try:
                   out = plan.process(torch.as_tensor(x32, device='cuda')).cpu().numpy().astype(np.float64)
               except _lib.OfxError as e:
                   if 'not supported' in str(e) or 'exceeds' in str(e) or 'covers' in str(e):
                       continue
                   raise
+              # time-domain window and psd_amp band of the (single-channel) events
+              tagw = f'case {c} N={n} pre={pre} B={B} eng={eng}/{plan.engine} td=[{wlo},{whi}) band=[{klo},{khi})'
+              seg = x64[:, wlo:whi]; sc = np.abs(x64).max(); ow = plan.tdwindow_offset(w)
+              assert np.allclose(out[:, ow + 0], seg.mean(axis=1), rtol=1e-4, atol=3e-6 * sc), tagw + ' baseline'
+              assert np.allclose(out[:, ow + 1], (seg.sum(axis=1) - 0.5 * (seg[:, 0] + seg[:, -1])) / FS, rtol=1e-4,
+                                 atol=3e-6 * sc * (whi - wlo) / FS), tagw + ' integral'
+              assert np.array_equal(out[:, ow + 2], seg.max(axis=1)) and np.array_equal(out[:, ow + 3], seg.min(axis=1)), \
+                  tagw + ' max/min'
+              V = np.fft.rfft(x64, axis=-1) / n
+              fold = np.abs(V) ** 2 * n / FS
+              fold[:, 1:(None if n % 2 else -1)] *= 2.0
+              want_band = np.sqrt(fold[:, klo:khi]).mean(axis=1)
+              assert np.allclose(out[:, plan.band_offset(band)], want_band, rtol=2e-4), tagw + ' psd_amp band'
               for s, (ft, filt) in enumerate(zip(fts, filts)):
                   tag = f'case {c} N={n} pre={pre} B={B} eng={eng}/{plan.engine} slot={s} win=[{lo},{hi}) out={outside} interp={interp}'
                   check_search(out, plan.search_offset(s, ids[s][0]), orc.process_events(filt, x64, 'nodelay', fcut), '', ft.ampres, FS, tag + ' nodelay')
