@@ -71,7 +71,18 @@ def run(cases, seed, verbose=True):
               for s, (ft, filt) in enumerate(zip(fts, filts)):
                   tag = f'case {c} N={n} pre={pre} B={B} eng={eng}/{plan.engine} slot={s} win=[{lo},{hi}) out={outside} interp={interp}'
                   check_search(out, plan.search_offset(s, ids[s][0]), orc.process_events(filt, x64, 'nodelay', fcut), '', ft.ampres, FS, tag + ' nodelay')
-                  check_search(out, plan.search_offset(s, ids[s][1]), orc.process_events(filt, x64, 'unconstrained', fcut, interpolate=interp), '', ft.ampres, FS, tag + ' delay', interpolated=interp)
+                  r1 = orc.process_events(filt, x64, 'unconstrained', fcut, interpolate=interp)
+                  # interpolated fits are checked on clear pulses only: the fp32 error of the sub-sample offset
+                  # scales as 1 / SNR (1e-3 sample at SNR ~ 30, the tolerance of tests/util.py)
+                  keep = np.abs(r1['amp']) > 50 * ft.ampres if interp else np.ones(B, bool)
+                  if keep.any():
+                      o1 = plan.search_offset(s, ids[s][1])
+                      dts = np.abs(out[keep, o1 + 1] - r1['t0'][keep]) * FS
+                      wz = int(np.argmax(dts))
+                      check_search(out[keep], o1, {kk: np.asarray(v)[keep] for kk, v in r1.items()}, '', ft.ampres, FS,
+                                   tag + f' delay (worst t0 error {dts[wz]:.2e} samples at snr {abs(r1["amp"][keep][wz]) / ft.ampres:.1f}, '
+                                         f'idx {out[keep, o1 + 7][wz]:.0f}/{r1["index"][keep][wz]}, t0 {out[keep, o1 + 1][wz]:.6e}/{r1["t0"][keep][wz]:.6e})',
+                                   interpolated=interp)
                   r = orc.process_events(filt, x64, 'constrained', fcut, window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)
                   if not np.any(r['index'] < 0):
                       check_search(out, plan.search_offset(s, ids[s][2]), r, '', ft.ampres, FS, tag + ' window')
@@ -270,7 +281,10 @@ def run_fused(cases, seed, verbose=True):
                 for q, (k, lo, hi, outside, interp) in enumerate(searches[s]):
                     o = offs[s][q]
                     flips = a[ok, o + 7] != b[ok, o + 7]
-                    assert flips.mean() <= 0.01, tag + f' slot {s} search {q}: {flips.sum()} bin flips'
+                    # a flipped bin must be a near tie: both engines see the same chi2 there
+                    assert flips.sum() <= max(1, 0.01 * flips.size), tag + f' slot {s} search {q}: {flips.sum()} bin flips'
+                    if flips.any():
+                        assert np.allclose(a[ok][flips, o + 2], b[ok][flips, o + 2], rtol=1e-5), tag + f' flip is not a tie s{s} q{q}'
                     same = ~flips
                     da = np.abs(a[ok][same, o] - b[ok][same, o])
                     lim = 1e-4 * np.abs(b[ok][same, o]) + 2e-4 * fts[s].ampres
@@ -296,7 +310,7 @@ def run_fused(cases, seed, verbose=True):
                     if np.all(r['index'] >= 0):
                         # the sub-sample offset of a noise peak is a ratio of amplitude differences far
                         # below fp32 resolution: interpolated fits are checked on clear pulses only
-                        keep = np.abs(r['amp']) > 20 * fts[s].ampres if interp else np.ones(len(sel), bool)
+                        keep = np.abs(r['amp']) > 50 * fts[s].ampres if interp else np.ones(len(sel), bool)
                         if keep.any():
                             rk = {kk: np.asarray(v)[keep] for kk, v in r.items()}
                             check_search(a[sel][keep], o, rk, '', fts[s].ampres, FS,
