@@ -36,6 +36,14 @@ int ofx_row_floats(const ofx_plan* p) {
     return n;
 }
 
+int ofx_rocfft_setup_once() {
+    static std::once_flag once;
+    static rocfft_status st = rocfft_status_success;
+    std::call_once(once, [] { st = rocfft_setup(); });
+    OFX_FFT(st);
+    return OFX_OK;
+}
+
 static void assign_offsets(ofx_plan* p) {
     int off = 0;
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
@@ -196,9 +204,7 @@ extern "C" int ofx_plan_set_filter(ofx_plan* p, int slot, const double* wf,
         return OFX_ERR_ARG;
     }
     OFX_HIP(hipSetDevice(p->device));
-    OfxSlotHost& h = p->slot[slot];
-    std::vector<OfxSearchDev> keep = h.searches;
-    free_slot(h);
+    // convert and validate first: a rejected table leaves the slot as it was
     const int K = p->K;
     std::vector<float2> wf32(K), s32(K);
     std::vector<float> g32(K);
@@ -207,12 +213,21 @@ extern "C" int ofx_plan_set_filter(ofx_plan* p, int slot, const double* wf,
         s32[k] = make_float2((float)s[2 * k], (float)s[2 * k + 1]);
         g32[k] = (float)g[k];
         if (!std::isfinite(wf32[k].x) || !std::isfinite(wf32[k].y) ||
+            !std::isfinite(s32[k].x) || !std::isfinite(s32[k].y) ||
             !std::isfinite(g32[k]) || g32[k] < 0) {
             ofx_set_error("ofx_plan_set_filter: non-finite / negative table entry at "
                           "bin %d (does the filter overflow fp32?)", k);
             return OFX_ERR_ARG;
         }
     }
+    OfxSlotHost& h = p->slot[slot];
+    std::vector<OfxSearchDev> keep = h.searches;
+    // the device tables of the old filter may still be read by a launch in flight
+    OFX_HIP(hipDeviceSynchronize());
+    free_slot(h);
+    h.searches = keep;
+    ++p->filter_stamp;              // whatever happens below, the slot tables are stale
+    assign_offsets(p);              // ... and the slot is unset until the upload has succeeded
     OFX_HIP(hipMalloc(&h.d_wf, sizeof(float2) * K));
     OFX_HIP(hipMalloc(&h.d_g, sizeof(float) * K));
     OFX_HIP(hipMalloc(&h.d_s, sizeof(float2) * K));
@@ -223,8 +238,6 @@ extern "C" int ofx_plan_set_filter(ofx_plan* p, int slot, const double* wf,
     h.tres_sum = tres_sum;
     h.g_host.assign(g, g + K);
     h.wf_host.assign(wf, wf + 2 * (size_t)K);
-    ++p->filter_stamp;
-    h.searches = keep;
     h.set = true;
     if (p->engine == OFX_ENGINE_FUSED) {
         int rc = ofx_fused_prepare_slot(p, slot, wf);

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,6 +34,21 @@ void ofx_set_error(const char* fmt, ...);
                           #expr, (int)s_);                                     \
             return OFX_ERR_HIP;                                                \
         }                                                                      \
+    } while (0)
+
+// Process-wide one-time initialisation, safe when plans are created from several threads.
+int ofx_rocfft_setup_once();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instantiation
+#define OFX_LDS_ATTR_ONCE(kernel, bytes)                                                   \
+    do {                                                                                   \
+        static std::once_flag once_;                                                       \
+        static hipError_t err_ = hipSuccess;                                               \
+        std::call_once(once_, [&] {                                                        \
+            err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                       (int)(bytes));                                      \
+        });                                                                                \
+        OFX_HIP(err_);                                                                     \
     } while (0)
 
 // ---------------------------------------------------------------- device view
@@ -164,6 +180,7 @@ struct ofx_plan {
     void* d_fused_slots = nullptr;       // FUSED multi-slot launches: slot table ...
     void* d_fused_spec = nullptr;        // ... and per-workgroup spectrum scratch
     size_t fused_spec_bytes = 0;
+    void* d_fused_xwide = nullptr;       // ... and per-workgroup stash of the bins 512 .. 4095 of 2 X_k
 
     // timing of the dominant kernel
     bool timing = false;

@@ -216,6 +216,15 @@ __device__ __forceinline__ void ofx_write_search(float* row, const OfxSearchDev&
                                                  int pre, float chi0, OfxCand best,
                                                  float lowchi2, const OfxRefined* ref = nullptr) {
     float* o = row + q.out_off;
+    if (best.idx == 0x7fffffff) {
+        // no lag compared greater than "none": the trace holds a NaN.  NumPy's argmin
+        // returns NaN features for such an event; a finite-looking row would hide it.
+        const float qnan = __int_as_float(0x7fc00000);
+#pragma unroll
+        for (int c = 0; c < OFX_SEARCH_FLOATS; ++c) o[c] = qnan;
+        o[OFX_COL_AMPRES] = sd.ampres;
+        return;
+    }
     const float amp = ref ? ref->amp : best.amp;
     o[OFX_COL_AMP] = amp;
     o[OFX_COL_T0] = ((float)(best.idx - pre) + (ref ? ref->frac : 0.0f)) * inv_fs;

@@ -61,7 +61,8 @@ constexpr int NV = 32 * VT;        // complex values per hardware thread
 constexpr int LD1 = 528;           // D1 row stride (elements); 528 = 16 mod 32
 constexpr int LD2 = 17;            // D2 row stride (elements)
 constexpr int XBUF_ELEMS = 1024 * LD2;            // 17408 >= 32*513, >= 16384
-constexpr int NLOW_MAX = 512;
+constexpr int NLOW_MAX = 512;         // low bins 2 X_k kept in LDS
+constexpr int NS_MAX = 4096;           // ... and up to here in the workgroup's global stash (WIDE)
 constexpr int NWAVE = FT / OFX_WAVE;
 
 // With two workgroups per CU every exchange runs in two passes through a half-size
@@ -146,16 +147,17 @@ __device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
 
 // ---- the pairwise middle step on one (Z_k, Z_p) slot -------------------------
 // in : zk = Z_k, zp = Z_p (p = M - k)      out: zk = Z'_k, zp = Z'_p
-// chi accumulates the chi2_0 contribution lane-wise (re^2 and im^2 terms); xk2 = 2 X_k.
+// chi accumulates the chi2_0 contribution lane-wise (re^2 and im^2 terms); xk2 = 2 X_k,
+// xp2 = 2 conj(X_p).
 // T = i t_k, tw = (W_k / 2, conj(W_p) / 2), g = (g_k', g_p').  20 packed instructions.
 __device__ __forceinline__ void mid_slot(cpx& zk, cpx& zp, const cpx T, const float4 tw,
-                                         const cpx g, cpx& xk2, cpx& chi) {
+                                         const cpx g, cpx& xk2, cpx& xp2, cpx& chi) {
     const cpx wk = lo2(tw), wp = hi2(tw);
     const cpx u = pfma(zp, mk(1.0f, -1.0f), zk);             // Z_k + conj(Z_p)
     const cpx w = pfma(zp, mk(-1.0f, 1.0f), zk);             // Z_k - conj(Z_p)
     const cpx sv = cmul(w, T);                               // i t w
     xk2 = u - sv;                                            // 2 X_k
-    const cpx xp2 = u + sv;                                  // 2 conj(X_p)
+    xp2 = u + sv;                                            // 2 conj(X_p)
     chi = pfma(xk2 * xk2, g.xx, chi);
     chi = pfma(xp2 * xp2, g.yy, chi);
     const cpx yk = cmul(xk2, wk);
@@ -222,8 +224,25 @@ __device__ __forceinline__ cpx perm_out(cpx (&d)[NV], bool z, cpx a8, const Fuse
 constexpr int MID_DEPTH = OFX_MID_DEPTH;
 struct MidRsrc {
     __amdgpu_buffer_rsrc_t w, g;
+    __amdgpu_buffer_rsrc_t xw;     // WIDE: this workgroup's stash of 2 X_k, k = 512 .. nstash-1
 };
-template <int O, int J, int NB>
+// WIDE kernels also keep the bins k >= NLOW_MAX a low-frequency chi2 cut-off or a psd_amp band
+// reaches (the reference's example YAML uses lowchi2_fcutoff = 50 kHz: 1311 bins at 32768
+// samples, examples/processing/process_example.yaml:113) in a per-workgroup stash in global
+// memory (L2-resident, entry k - 512).  Who holds bin k:  slot J of virtual thread v has
+// xk2 = 2 X_k for k = v + 1024 J and xp2 = 2 conj(X_p) for p = 1024 (16 - J) - v (v != 0);
+// virtual thread 0's slots J >= 8 hold block 512: k = 512 + 1024 (J - 8).  The descriptor is
+// sized to the bins the plan needs (and empty for the slots after the first of a MULTI
+// launch): stores beyond it are dropped by the bounds check, so there are no branches here.
+// The B-side entries stay conjugated; the reader undoes that ((k & 1023) > 512).
+constexpr int OOB_OFF = 0x40000000;
+__device__ __forceinline__ void buf_st2(__amdgpu_buffer_rsrc_t r, cpx x, int voff) {
+    u32x2 v;
+    v.x = __float_as_uint(x.x);
+    v.y = __float_as_uint(x.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, 0, 0);
+}
+template <int O, int J, int NB, bool WIDE>
 __device__ __forceinline__ void mid_unrolled(cpx (&d)[NV], const MidRsrc& r, int v, FusedLds& L,
                                              cpx tlo, cpx thi, float4 (&tw)[NB], cpx (&tg)[NB],
                                              cpx& chi) {
@@ -233,13 +252,21 @@ __device__ __forceinline__ void mid_unrolled(cpx (&d)[NV], const MidRsrc& r, int
             tg[(J + MID_DEPTH) % NB] = buf_ld2(r.g, v * 8, (J + MID_DEPTH) * 4096);
         }
         const cpx T = twmul<J, -1>(J < 8 ? tlo : thi);
-        cpx xk2;
-        mid_slot(d[O + J], d[O + 16 + 15 - J], T, tw[J % NB], tg[J % NB], xk2, chi);
+        cpx xk2, xp2;
+        mid_slot(d[O + J], d[O + 16 + 15 - J], T, tw[J % NB], tg[J % NB], xk2, xp2, chi);
         if constexpr (J == 0) L.xlow[v] = xk2;               // 2 X_k, k = v < 512
-        mid_unrolled<O, J + 1, NB>(d, r, v, L, tlo, thi, tw, tg, chi);
+        if constexpr (WIDE) {
+            if constexpr (J >= 1 && 1024 * J < NS_MAX)
+                buf_st2(r.xw, xk2, (v + 1024 * J - NLOW_MAX) * 8);
+            if constexpr (1024 * (15 - J) + 512 < NS_MAX)
+                buf_st2(r.xw, xp2, v == 0 ? OOB_OFF : (1024 * (16 - J) - v - NLOW_MAX) * 8);
+            if constexpr (O == 0 && J >= 8 && 512 + 1024 * (J - 8) < NS_MAX)
+                buf_st2(r.xw, xk2, v == 0 ? 1024 * (J - 8) * 8 : OOB_OFF);
+        }
+        mid_unrolled<O, J + 1, NB, WIDE>(d, r, v, L, tlo, thi, tw, tg, chi);
     }
 }
-template <int O>
+template <int O, bool WIDE>
 __device__ __forceinline__ cpx middle_slots(cpx (&d)[NV], const MidRsrc& r, int v, FusedLds& L,
                                             cpx tlo, cpx thi, cpx chi) {
     constexpr int NB = MID_DEPTH + 1;
@@ -250,7 +277,7 @@ __device__ __forceinline__ cpx middle_slots(cpx (&d)[NV], const MidRsrc& r, int 
         tw[j] = buf_ld4(r.w, v * 16, j * 8192);
         tg[j] = buf_ld2(r.g, v * 8, j * 4096);
     }
-    mid_unrolled<O, 0, NB>(d, r, v, L, tlo, thi, tw, tg, chi);
+    mid_unrolled<O, 0, NB, WIDE>(d, r, v, L, tlo, thi, tw, tg, chi);
     return chi;
 }
 
@@ -270,8 +297,8 @@ __device__ __forceinline__ void mid_staged_unrolled(cpx (&d)[NV], const MidRsrc&
             zn = xs[(15 - (J + 1)) * FT];
         }
         const cpx T = twmul<J, -1>(J < 8 ? tlo : thi);
-        cpx xk2;
-        mid_slot(d[O + J], zp, T, tw[J & 1], tg[J & 1], xk2, chi);
+        cpx xk2, xp2;
+        mid_slot(d[O + J], zp, T, tw[J & 1], tg[J & 1], xk2, xp2, chi);
         xs[(15 - J) * FT] = zp;
         if constexpr (J == 0) L.xlow[v] = xk2;               // 2 X_k, k = v < 512
         mid_staged_unrolled<O, J + 1>(d, r, v, L, xs, tlo, thi, tw, tg, zn, chi);
@@ -342,6 +369,8 @@ struct Roles {
 //             interpolate (neighbour amplitudes of the winner)
 // FEAT bit 1: plan has time-domain windows
 // FEAT bit 2: channel algebra on load (sum_j weight_j * channel_j)
+// FEAT bit 3: WIDE -- a lowchi2 cut-off or psd_amp band reaches beyond NLOW_MAX bins: bins
+//             512 .. nstash-1 of 2 X_k go through this workgroup's stash `xwide`
 // MULTI: several filter slots (template_tag x csd_tag) share the forward transform of a
 //        trace: the spectrum (state after F3) is parked in a per-workgroup scratch area
 //        (128 KiB, L2 / MALL resident) and every slot runs middle -> inverse -> tail on
@@ -353,7 +382,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                                                  const uint8_t* __restrict__ valid,
                                                  long long n_traces, float* __restrict__ out,
                                                  const FusedSlotArg* __restrict__ slots,
-                                                 int nslots, float2* __restrict__ spec) {
+                                                 int nslots, float2* __restrict__ spec,
+                                                 float2* __restrict__ xwide, int nstash) {
+    constexpr bool WIDE = (FEAT & 8) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     FusedLds& L = *reinterpret_cast<FusedLds*>(smem_raw);
     const int tid = threadIdx.x;
@@ -707,7 +738,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         for (int slot_i = 0; slot_i < slot_n; ++slot_i) {
         // ------------------------------------------- F3, middle, I3 (registers)
         const MidRsrc rmid = {make_rsrc(TBX.midW, 16 * 512 * 16),
-                              make_rsrc(TBX.midG, 16 * 512 * 8)};
+                              make_rsrc(TBX.midG, 16 * 512 * 8),
+                              make_rsrc(xwide + (WIDE ? (size_t)blockIdx.x * (NS_MAX - NLOW_MAX) : 0),
+                                        (WIDE && slot_i == 0) ? (nstash - NLOW_MAX) * 8 : 0)};
         cpx chi2v = mk(0.0f, 0.0f);
         constexpr bool STAGE_B = (VT == 1) && SPLIT_EXCHANGE;
         if constexpr (STAGE_B) {
@@ -738,7 +771,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
             const cpx tb = buf_ld2(rtb, tl * 8, 0);
             const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
-            chi2v = middle_slots<0>(d, rmid, tl, L, tb, tbh, chi2v);
+            chi2v = middle_slots<0, WIDE>(d, rmid, tl, L, tb, tbh, chi2v);
             if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, TBX, chi2v, L.perm);
             dft<16, +1, NV, 0>(d);
             dft<16, +1, NV, 16>(d);
@@ -750,7 +783,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 dft<16, -1, NV, O + 16>(d);
             }
             const cpx tb = buf_ld2(rtb, (tl + FT) * 8, 0);
-            chi2v = middle_slots<O>(d, rmid, tl + FT, L, tb, tb, chi2v);
+            chi2v = middle_slots<O, WIDE>(d, rmid, tl + FT, L, tb, tb, chi2v);
             dft<16, +1, NV, O>(d);
             dft<16, +1, NV, O + 16>(d);
         }
@@ -947,14 +980,20 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             __syncthreads();
         }
 
-        // psd_amp bands from the stashed 2 X_k (k < NLOW_MAX); one wave per band
+        // psd_amp bands from the stashed 2 X_k (LDS below NLOW_MAX, the global stash above);
+        // one wave per band
+        const __amdgpu_buffer_rsrc_t rxw =
+            make_rsrc(xwide + (WIDE ? (size_t)blockIdx.x * (NS_MAX - NLOW_MAX) : 0),
+                      WIDE ? (nstash - NLOW_MAX) * 8 : 0);
         if (pd.n_bands > 0 && slot_i == 0) {
             const float cpsd = 0.25f / ((float)FN * pd.fs);      // (2 X)^2 / 4 / (N fs)
             for (int i = wave_t; i < pd.n_bands; i += NWAVE) {
                 const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
                 float acc = 0.0f;
                 for (int k = lo + lane_t; k < hi; k += 64) {
-                    const cpx x2 = L.xlow[k];
+                    cpx x2;
+                    if (!WIDE || k < NLOW_MAX) x2 = L.xlow[k];
+                    else x2 = buf_ld2(rxw, (k - NLOW_MAX) * 8, 0);
                     acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
                 }
                 acc = ofx_wave_sum(acc);
@@ -962,11 +1001,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
         }
 
-        // Per search: resolve the fit and every thread's share of the low-frequency chi2
-        // (the last consumers of VMEM-loaded values), parked per wave in LDS ...
-#pragma unroll 1
-        for (int q = 0; q < SDX.n_search; ++q) {
-            const OfxSearchDev& sq = SDX.search[q];
+        // The fit of search q (uniform): no-delay lag, full-range winner or window winner.
+        auto resolve = [&](const OfxSearchDev& sq, int q) {
             OfxCand best;
             const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
                               sq.hi == FN;
@@ -980,32 +1016,49 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 if constexpr (FEAT & 1) best = L.sres[q];
                 else best = ofx_cand_none();
             }
+            return best;
+        };
+        // interpolate=True: amplitudes at the rolled bins idx -+ 1 (the last readers of d)
+        if constexpr (FEAT & 1) {
+#pragma unroll 1
+            for (int q = 0; q < SDX.n_search; ++q) {
+                const OfxSearchDev& sq = SDX.search[q];
+                if (!sq.interp) continue;  // uniform
+                const OfxCand best = resolve(sq, q);
+                // lag n = 1024 n1 + 2 vt + e sits in thread vt % FT, register
+                // 32 (vt / FT) + n1, component e: only the owning thread looks
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int n = (best.idx + (side ? 1 : -1) - pre) & (FN - 1);
+                    const int vt_n = (n & 1023) >> 1;
+                    if (tt == (vt_n & (FT - 1))) {
+                        const int jn = 32 * (vt_n / FT) + (n >> 10);
+                        cpx v = d[0];
+#pragma unroll
+                        for (int j = 1; j < NV; ++j) v = (j == jn) ? d[j] : v;
+                        L.nb[q][side] = (n & 1) ? v.y : v.x;
+                    }
+                }
+                __syncthreads();
+                const OfxRefined ref = ofx_interpolate(L.nb[q][0], best.amp, L.nb[q][1], best.idx,
+                                                       FN, SDX.norm, chi0);
+                if (tt == 0) L.ref[q] = ref;
+            }
+            __syncthreads();
+        }
+        // Per search: every thread's share of the low-frequency chi2 (the last consumers of
+        // VMEM-loaded values), parked per wave in LDS ...
+#pragma unroll 1
+        for (int q = 0; q < SDX.n_search; ++q) {
+            const OfxSearchDev& sq = SDX.search[q];
+            const OfxCand best = resolve(sq, q);
             const int dl = best.idx - pre;
             OfxRefined ref;
             ref.amp = best.amp;
             ref.frac = 0.0f;
             ref.chi2 = 0.0f;
-            if constexpr (FEAT & 1) {
-                if (sq.interp) {           // uniform: amplitudes at the rolled bins idx -+ 1
-                    // lag n = 1024 n1 + 2 vt + e sits in thread vt % FT, register
-                    // 32 (vt / FT) + n1, component e: only the owning thread looks
-#pragma unroll
-                    for (int side = 0; side < 2; ++side) {
-                        const int n = (best.idx + (side ? 1 : -1) - pre) & (FN - 1);
-                        const int vt_n = (n & 1023) >> 1;
-                        if (tt == (vt_n & (FT - 1))) {
-                            const int jn = 32 * (vt_n / FT) + (n >> 10);
-                            cpx v = d[0];
-#pragma unroll
-                            for (int j = 1; j < NV; ++j) v = (j == jn) ? d[j] : v;
-                            L.nb[q][side] = (n & 1) ? v.y : v.x;
-                        }
-                    }
-                    __syncthreads();
-                    ref = ofx_interpolate(L.nb[q][0], best.amp, L.nb[q][1], best.idx, FN, SDX.norm, chi0);
-                    if (tt == 0) L.ref[q] = ref;
-                }
-            }
+            if constexpr (FEAT & 1)
+                if (sq.interp) ref = L.ref[q];
             float low = 0.0f;
 #pragma unroll
             for (int i = 0; i < NLK; ++i) {
@@ -1021,6 +1074,55 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             low = ofx_wave_sum(low);
             if (lane_t == 0) L.lowp[q][wave_t] = low;
             if (tt == 0) L.fin[q] = best;
+        }
+        // ... WIDE: the bins from NLOW_MAX up, in chunks of WCH per thread read back from the
+        // stash (entries of the partner blocks are conjugated, see MidRsrc) with their table
+        // rows; every search with a cut-off beyond the chunk's first bin adds its share
+        if constexpr (WIDE) {
+            constexpr int WCH = 4;
+            const __amdgpu_buffer_rsrc_t rw_s = make_rsrc(SDX.s, NS_MAX * 8);
+            const __amdgpu_buffer_rsrc_t rw_g = make_rsrc(SDX.g, NS_MAX * 4);
+            int nmax = 0;
+#pragma unroll 1
+            for (int q = 0; q < SDX.n_search; ++q) nmax = max(nmax, SDX.search[q].nlow);
+#pragma unroll 1
+            for (int k0 = NLOW_MAX; k0 < nmax; k0 += WCH * FT) {
+                cpx wx[WCH], wsv[WCH];
+                float wg[WCH];
+#pragma unroll
+                for (int i = 0; i < WCH; ++i) {
+                    const int k = k0 + tt + FT * i;
+                    wx[i] = buf_ld2(rxw, (k - NLOW_MAX) * 8, 0);
+                    wsv[i] = buf_ld2(rw_s, k * 8, 0);
+                    wg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw_g, k * 4, 0, 0));
+                }
+#pragma unroll 1
+                for (int q = 0; q < SDX.n_search; ++q) {
+                    const OfxSearchDev& sq = SDX.search[q];
+                    if (sq.nlow <= k0) continue;                         // uniform
+                    const OfxCand best = resolve(sq, q);
+                    const int dl = best.idx - pre;
+                    float amp = best.amp, frac = 0.0f;
+                    if constexpr (FEAT & 1)
+                        if (sq.interp) {
+                            amp = L.ref[q].amp;
+                            frac = L.ref[q].frac;
+                        }
+                    float low = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) {
+                        const int k = k0 + tt + FT * i;
+                        if (k < sq.nlow) {
+                            const float sgn = ((k & 1023) > 512) ? -0.5f : 0.5f;
+                            low += ofx_lowchi2_term(k, FN, dl, amp,
+                                                    make_float2(0.5f * wx[i].x, sgn * wx[i].y),
+                                                    make_float2(wsv[i].x, wsv[i].y), wg[i], frac);
+                        }
+                    }
+                    low = ofx_wave_sum(low);
+                    if (lane_t == 0) L.lowp[q][wave_t] += low;           // same lane wrote it above
+                }
+            }
         }
         STAMP(11);                               // tail A: max, reductions, arg-max, lowchi2 terms
         // ... then d and every table value are dead: request the next trace.  Nothing
@@ -1063,7 +1165,8 @@ int ofx_fused_release(ofx_plan* p) {
     p->d_tw1 = p->d_tw2 = nullptr;
     if (p->d_fused_slots) (void)hipFree(p->d_fused_slots);
     if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
-    p->d_fused_slots = p->d_fused_spec = nullptr;
+    if (p->d_fused_xwide) (void)hipFree(p->d_fused_xwide);
+    p->d_fused_slots = p->d_fused_spec = p->d_fused_xwide = nullptr;
     p->fused_spec_bytes = 0;
     return OFX_OK;
 }
@@ -1150,14 +1253,10 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
 template <int FEAT, bool MULTI>
 static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const FusedTabs& tabs,
                   const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
-                  hipStream_t st, const FusedSlotArg* d_slots, int nslots) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT, MULTI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)sizeof(FusedLds)));
-        attr_set = true;
-    }
+                  hipStream_t st, const FusedSlotArg* d_slots, int nslots, int nstash) {
+    // (100 KiB covers the diagnostic one-workgroup-per-CU launch below as well)
+    OFX_LDS_ATTR_ONCE((k_fused<FEAT, MULTI>),
+                      sizeof(FusedLds) > 100 * 1024 ? sizeof(FusedLds) : 100 * 1024);
     long long grid = (long long)p->cu_count * WG_PER_CU;
     size_t lds_bytes = sizeof(FusedLds);
     // diagnostic: OFX_DIAG_WGPC=1 runs one workgroup per CU (uncontended phase times)
@@ -1165,13 +1264,6 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
     if (diag_wgpc == 1) {
         grid = p->cu_count;
         lds_bytes = 100 * 1024;
-        static bool attr2 = false;
-        if (!attr2) {
-            OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused<FEAT, MULTI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes));
-            attr2 = true;
-        }
     }
     if (MULTI) {
         // per-workgroup spectrum scratch (sized for the full grid, allocated once)
@@ -1184,13 +1276,17 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
             p->fused_spec_bytes = need;
         }
     }
+    if ((FEAT & 8) && !p->d_fused_xwide)   // per-workgroup stash of the bins 512 .. NS_MAX-1
+        OFX_HIP(hipMalloc(&p->d_fused_xwide, (size_t)p->cu_count * WG_PER_CU *
+                                                 (NS_MAX - NLOW_MAX) * sizeof(float2)));
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
     hipLaunchKernelGGL((k_fused<FEAT, MULTI>), dim3((unsigned)grid), dim3(FT), lds_bytes, st, pd,
                        sd, tabs, d_traces, d_valid, n, d_out, d_slots, nslots,
-                       reinterpret_cast<float2*>(p->d_fused_spec));
+                       reinterpret_cast<float2*>(p->d_fused_spec),
+                       reinterpret_cast<float2*>(p->d_fused_xwide), nstash);
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
@@ -1201,17 +1297,19 @@ template <bool MULTI>
 static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd,
                        const FusedTabs& tabs, const float* d_traces, const uint8_t* d_valid,
                        long long n, float* d_out, hipStream_t st, const FusedSlotArg* d_slots,
-                       int nslots) {
-    switch (feat) {
-        case 0: return launch<0, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        case 1: return launch<1, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        case 2: return launch<2, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        case 3: return launch<3, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        case 4: return launch<4, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        case 5: return launch<5, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        case 6: return launch<6, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
-        default: return launch<7, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots);
+                       int nslots, int nstash) {
+#define OFX_CASE(F)                                                                            \
+    case F:                                                                                    \
+        return launch<F, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,     \
+                                nslots, nstash);
+    switch (feat & 15) {
+        OFX_CASE(0) OFX_CASE(1) OFX_CASE(2) OFX_CASE(3) OFX_CASE(4) OFX_CASE(5) OFX_CASE(6)
+        OFX_CASE(7) OFX_CASE(8) OFX_CASE(9) OFX_CASE(10) OFX_CASE(11) OFX_CASE(12) OFX_CASE(13)
+        OFX_CASE(14)
+        default: return launch<15, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st,
+                                          d_slots, nslots, nstash);
     }
+#undef OFX_CASE
 }
 
 // One launch per call: a plan with several filter slots runs them all on the shared
@@ -1236,6 +1334,7 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
 
     std::vector<FusedSlotArg> args;
     int feat = 0;
+    int nstash = 0;                 // bins of 2 X_k the tail reads back
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
         if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
         FusedSlotArg a;
@@ -1251,11 +1350,12 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             if (sq.kind == OFX_SEARCH_DELAY &&
                 (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
                 feat |= 1;
-            if (sq.nlow > NLOW_MAX) {
+            if (sq.nlow > NS_MAX || (sq.nlow > NLOW_MAX && VT != 2)) {
                 ofx_set_error("FUSED engine: lowchi2_fcutoff covers %d bins (> %d)", sq.nlow,
-                              NLOW_MAX);
+                              VT == 2 ? NS_MAX : NLOW_MAX);
                 return OFX_ERR_UNSUPPORTED;
             }
+            if (sq.nlow > nstash) nstash = sq.nlow;
         }
         args.push_back(a);
     }
@@ -1267,13 +1367,16 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             return OFX_ERR_UNSUPPORTED;
         }
         for (int i = 0; i < pd.n_bands; ++i)
-            if (pd.band[i].k_hi > NLOW_MAX) {
+            if (pd.band[i].k_hi > (VT == 2 ? NS_MAX : NLOW_MAX)) {
                 ofx_set_error("FUSED engine: band [%d,%d) exceeds the %d stashed bins",
-                              pd.band[i].k_lo, pd.band[i].k_hi, NLOW_MAX);
+                              pd.band[i].k_lo, pd.band[i].k_hi, VT == 2 ? NS_MAX : NLOW_MAX);
                 return OFX_ERR_UNSUPPORTED;
+            } else if (pd.band[i].k_hi > nstash) {
+                nstash = pd.band[i].k_hi;
             }
     }
     if (pd.n_tdwin > 0) feat |= 2;
+    if (nstash > NLOW_MAX) feat |= 8;
     if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
 
     if (nslots <= 1) {
@@ -1285,7 +1388,7 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             tabs = args[0].tabs;
         }
         return launch_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, nullptr,
-                                  nslots);
+                                  nslots, nstash);
     }
     // several slots: upload the slot table (from a buffer owned by the plan: the copy is
     // asynchronous on the stream)
@@ -1303,5 +1406,6 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     OfxSlotDev sd0;
     memset(&sd0, 0, sizeof(sd0));
     return launch_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,
-                             reinterpret_cast<const FusedSlotArg*>(p->d_fused_slots), nslots);
+                             reinterpret_cast<const FusedSlotArg*>(p->d_fused_slots), nslots,
+                             nstash);
 }

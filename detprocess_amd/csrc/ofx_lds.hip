@@ -618,12 +618,7 @@ template <int BT, bool PF, int MAXR = 16>
 static int launch_lds(ofx_plan* p, const OfxPlanDev& pd, const LdsGeom& g, int nslots,
                       const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
                       hipStream_t st, size_t lds) {
-    static size_t attr_done = 0;
-    if (attr_done < lds) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds<BT, PF, MAXR>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-        attr_done = LDS_BUDGET;
-    }
+    OFX_LDS_ATTR_ONCE((k_lds<BT, PF, MAXR>), LDS_BUDGET);
     int per_cu = (int)((160 * 1024) / lds);
     const int by_threads = 1024 / BT;
     if (per_cu > by_threads) per_cu = by_threads;
@@ -824,12 +819,7 @@ struct OfxLdsFft {
 namespace {
 template <int BT, bool FWD, int MAXR = 16>
 int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        OFX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_fft<BT, FWD, MAXR>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-        attr_done = true;
-    }
+    OFX_LDS_ATTR_ONCE((k_lds_fft<BT, FWD, MAXR>), LDS_BUDGET);
     int per_cu = (int)((160 * 1024) / f->lds);
     if (per_cu > 1024 / BT) per_cu = 1024 / BT;
     if (per_cu < 1) per_cu = 1;

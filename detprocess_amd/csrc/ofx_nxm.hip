@@ -301,10 +301,9 @@ int ensure_stage_in(ofx_nxm* p, size_t floats, hipStream_t st) {
 int get_fft(ofx_nxm* p, long long nb, hipStream_t st, NxmFft** out) {
     auto it = p->fft.find(nb);
     if (it == p->fft.end()) {
-        static bool setup_done = false;
-        if (!setup_done) {
-            OFX_FFT(rocfft_setup());
-            setup_done = true;
+        {
+            const int rc_setup = ofx_rocfft_setup_once();
+            if (rc_setup) return rc_setup;
         }
         NxmFft f;
         const size_t len = (size_t)p->N / 2;             // packed complex points

@@ -251,10 +251,9 @@ __global__ __launch_bounds__(RB) void k_search(OfxPlanDev pd, OfxSlotDev sd,
 static int get_fft(ofx_plan* p, int batch, hipStream_t st, OfxFftPlans** out) {
     auto it = p->fft.find(batch);
     if (it == p->fft.end()) {
-        static bool setup_done = false;
-        if (!setup_done) {
-            OFX_FFT(rocfft_setup());
-            setup_done = true;
+        {
+            const int rc_setup = ofx_rocfft_setup_once();
+            if (rc_setup) return rc_setup;
         }
         OfxFftPlans f;
         size_t len = (size_t)p->N / 2;           // packed complex points

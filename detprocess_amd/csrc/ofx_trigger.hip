@@ -237,10 +237,9 @@ int make_plans(ofx_trigger* t, long long nblk, hipStream_t st) {
     if (t->info) rocfft_execution_info_destroy(t->info);
     t->r2c = t->c2r = nullptr;
     t->info = nullptr;
-    static bool setup_done = false;
-    if (!setup_done) {
-        OFX_FFT(rocfft_setup());
-        setup_done = true;
+    {
+        const int rc_setup = ofx_rocfft_setup_once();
+        if (rc_setup) return rc_setup;
     }
     const size_t len = (size_t)t->P;
     OFX_FFT(rocfft_plan_create(&t->r2c, rocfft_placement_notinplace,

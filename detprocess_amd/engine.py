@@ -168,7 +168,7 @@ class OFPlan:
             out = torch.empty((B, row), dtype=torch.float32, device=traces.device)
         v_ptr = None
         if valid is not None:
-            valid = valid.to(device=traces.device, dtype=torch.uint8).contiguous()
+            valid = torch.as_tensor(valid).to(device=traces.device, dtype=torch.uint8).contiguous()
             v_ptr = valid.data_ptr()
         stream = torch.cuda.current_stream(traces.device).cuda_stream
         _lib.check(self._lib.ofx_process(self._h, traces.data_ptr(), v_ptr, B,

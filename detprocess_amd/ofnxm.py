@@ -174,7 +174,7 @@ class NxMPlan:
         out = torch.empty((b, row), dtype=torch.float32, device=ev.device)
         v_ptr = None
         if valid is not None:
-            valid = valid.to(device=ev.device, dtype=torch.uint8).contiguous()
+            valid = torch.as_tensor(valid).to(device=ev.device, dtype=torch.uint8).contiguous()
             v_ptr = valid.data_ptr()
         stream = torch.cuda.current_stream(ev.device).cuda_stream
         _lib.check(self._lib.ofx_nxm_process(self._h, ev.data_ptr(), v_ptr, b, _lib.MEM_DEVICE,

@@ -29,7 +29,7 @@ OF_ALGORITHMS = {
                                     "ampres", "timeres")),
 }
 TD_ALGORITHMS = ("baseline", "integral", "maximum", "minimum")
-FUSED_MAX_BAND_BIN = 512       # bins the FUSED engine keeps for psd_amp / lowchi2
+FUSED_MAX_BAND_BIN = 4096      # bins the FUSED engine keeps for psd_amp / lowchi2 (LDS + stash)
 # algorithms whose base name contains one of these get an OFBase in the reference
 # (processing_data.py:93-97); the ones not implemented here raise explicitly
 OF_BASE_PREFIXES = ["of1x1", "of1x2x2", "of1x3x3", "ofnxm", "ofnxmx2", "psd_amp",
@@ -125,6 +125,9 @@ class FeatureProcessing:
                         raise ValueError(f"ERROR: Missing parameter weight {key} for "
                                          f"channel {channel}!")     # processing_data.py:982-986
                     w[j] = weights_all[channel][key]
+            if sep is None:
+                w[:] = 1.0         # get_channel_trace ignores weights without a separator
+                                   # (processing_data.py:1033-1047)
             if sep == "-":
                 if len(names) != 2:
                     raise ValueError('ERROR: "-" needs exactly two channels')
@@ -230,8 +233,10 @@ class FeatureProcessing:
                         if skey not in slots:
                             slot = len(slots)
                             tag, csd_tag, coupling, peaks, harm, inorm = skey
-                            # filter lookup uses the first physical channel of the expression
-                            fchan = channel if channel in self._filter_data._filter_data else names[0]
+                            # the filter file is looked up with the YAML channel expression
+                            # itself ('A+B' needs its own template / csd entry) and raises
+                            # 'Channel ... not available' otherwise: processing_data.py:295, 345
+                            fchan = channel
                             template, _, tmeta = self._filter_data.get_template(
                                 fchan, tag=tag, return_metadata=True)
                             csd, _, cmeta = self._filter_data.get_csd(
@@ -501,8 +506,7 @@ class FeatureProcessing:
             extractor = getattr(self._ext, base)
             if needs_of:
                 from .ofbase import OFBase
-                fchan = (cp.channel if cp.channel in self._filter_data._filter_data
-                         else cp.chan_names[0])
+                fchan = cp.channel        # exact expression, as processing_data.py:295, 345
                 ob = OFBase(self._fs, device=self._device, engine=self._engine)
                 csd, _, _ = self._filter_data.get_csd(fchan, tag=params.get("csd_tag", "default"),
                                                       fold=False, return_metadata=True)

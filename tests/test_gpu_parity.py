@@ -193,20 +193,72 @@ def test_adc_cut_and_convert_front_end(n, engine):
     check_search(out[ok].astype(np.float64), 0, ref, "", ft.ampres, FS, f"adc/{engine}")
 
 
-def test_auto_engine_falls_back_for_wide_lowchi2():
-    """lowchi2_fcutoff = 50 kHz covers 1311 bins; the FUSED kernel stashes 512, so an
-    AUTO plan runs that call on the general engine (an explicit FUSED plan refuses)."""
+def test_fused_handles_wide_lowchi2_and_bands():
+    """lowchi2_fcutoff = 50 kHz -- the value the reference's example YAML uses on every OF
+    algorithm (examples/processing/process_example.yaml:113-340) -- covers 1311 bins at 32768
+    samples.  The FUSED kernel keeps bins 0..511 in LDS and the rest in a per-workgroup stash
+    (up to 4096 bins); several cut-offs on one slot, interpolation, psd_amp bands beyond bin
+    512 and multi-slot plans all stay on it.  Beyond 4096 bins an AUTO plan runs the call on
+    the general engine and an explicit FUSED plan refuses."""
     from detprocess_amd import _lib
     n = 32768
-    plan, ft, filt, tmpl, psd = _mk(n, engine="auto")
-    sid = plan.add_search(0, "delay", lowchi2_fcutoff=50000.0)
-    x, _, _ = synth.make_traces(7, tmpl, psd, FS, ft.ampres, seed=9)
-    x32 = x.astype(np.float32)
+    for engine in ("fused", "auto"):
+        plan, ft, filt, tmpl, psd = _mk(n, engine=engine)
+        s1 = plan.add_search(0, "delay", lowchi2_fcutoff=50000.0)
+        s2 = plan.add_search(0, "nodelay", lowchi2_fcutoff=30000.0)
+        s3 = plan.add_search(0, "delay", 16000, 17000, lowchi2_fcutoff=156000.0)   # 4090 bins
+        s4 = plan.add_search(0, "delay", lowchi2_fcutoff=10000.0)
+        s5 = plan.add_search(0, "delay", 15800, 17200, lowchi2_fcutoff=39100.0, interpolate=True)
+        b1 = plan.add_band(400, 700)
+        b2 = plan.add_band(1000, 3100)
+        assert plan.engine == "fused"
+        x, _, _ = synth.make_traces(600, tmpl, psd, FS, ft.ampres, seed=9)
+        x32 = x.astype(np.float32)
+        x64 = x32.astype(np.float64)
+        out = _run(plan, x32)
+        for sid, mode, kw, fc in [
+                (s1, "unconstrained", {}, 50000.0), (s2, "nodelay", {}, 30000.0),
+                (s3, "constrained", dict(window_min_index=16000, window_max_index=17000), 156000.0),
+                (s4, "unconstrained", {}, 10000.0)]:
+            ref = orc.process_events(filt, x64, mode, lowchi2_fcutoff=fc, **kw)
+            check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, f"{engine}/{fc}")
+        ref = orc.process_events(filt, x64, "constrained", lowchi2_fcutoff=39100.0, interpolate=True,
+                                 window_min_index=15800, window_max_index=17200)
+        hi = np.abs(ref["amp"]) > 50 * ft.ampres
+        sub = {k: np.asarray(v)[hi] for k, v in ref.items() if np.ndim(v) == 1 and len(v) == len(hi)}
+        check_search(out[hi], plan.search_offset(0, s5), sub, "", ft.ampres, FS, f"{engine}/interp",
+                     interpolated=True)
+        for bid, (lo, hi_) in ((b1, (400, 700)), (b2, (1000, 3100))):
+            # algorithms.py:1013-1038 on one-sided bins [lo, hi): sqrt(2 |FFT/N|^2 N / fs), averaged
+            V = np.fft.rfft(x64, axis=-1)[:, lo:hi_] / n
+            want = np.sqrt(2.0 * np.abs(V) ** 2 * n / FS).mean(axis=-1)
+            assert np.allclose(out[:, plan.band_offset(bid)], want, rtol=2e-5), (engine, lo, hi_)
+        plan.close()
+    # the same on a three-slot plan (the stash is written once, by the first slot's pass)
+    plan, ft, filt, tmpl, psd = _mk(n, engine="fused")
+    tm2 = np.roll(tmpl, 3) * 0.5 + 0.5 * tmpl
+    tm2 /= tm2.max()
+    from detprocess_amd import build_filter
+    ft2 = build_filter(tm2, psd, FS, n // 2)
+    plan.set_filter(1, ft2)
+    plan.set_filter(2, ft)
+    ids = [plan.add_search(s, "delay", lowchi2_fcutoff=fc) for s, fc in ((0, 50000.0), (1, 80000.0), (2, 5000.0))]
+    x32 = x[:40].astype(np.float32)
     out = _run(plan, x32)
-    ref = orc.process_events(filt, x32.astype(np.float64), "unconstrained", lowchi2_fcutoff=50000.0)
-    check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, "auto/50kHz")
+    assert plan.engine == "fused"
+    for s, fc, f_ in ((0, 50000.0, filt), (1, 80000.0, orc.OFFilter(tm2, psd, FS, n // 2)), (2, 5000.0, filt)):
+        ref = orc.process_events(f_, x32.astype(np.float64), "unconstrained", lowchi2_fcutoff=fc)
+        check_search(out, plan.search_offset(s, ids[s]), ref, "", 1.0 / np.sqrt(f_.norm), FS, f"multi/{fc}")
+    plan.close()
+    # beyond the stash: AUTO falls back for that call, FUSED refuses
+    plan, ft, filt, tmpl, psd = _mk(n, engine="auto")
+    sid = plan.add_search(0, "delay", lowchi2_fcutoff=200000.0)
+    x32 = x[:7].astype(np.float32)
+    out = _run(plan, x32)
+    ref = orc.process_events(filt, x32.astype(np.float64), "unconstrained", lowchi2_fcutoff=200000.0)
+    check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, "auto/200kHz")
     plan2, *_ = _mk(n, engine="fused")
-    plan2.add_search(0, "delay", lowchi2_fcutoff=50000.0)
+    plan2.add_search(0, "delay", lowchi2_fcutoff=200000.0)
     with pytest.raises(_lib.OfxError):
         _run(plan2, x32)
 
