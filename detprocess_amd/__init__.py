@@ -1,6 +1,6 @@
 """detprocess_amd -- MI355X-native engine for the detprocess of1x1 feature-extraction hot path."""
 
-from .engine import OFPlan, synth_traces          # noqa: F401
+from .engine import OFPlan, SynthSource, synth_traces   # noqa: F401
 from .filters import FilterTables, build_filter   # noqa: F401
 from .algorithms import FeatureExtractors         # noqa: F401
 from .config import YamlConfig                    # noqa: F401

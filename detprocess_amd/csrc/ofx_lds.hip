@@ -43,7 +43,9 @@ struct LdsGeom {
     int fac[LDS_MAX_FAC];
     unsigned magic[LDS_MAX_FAC];   // floor(2^32 / stride) + 1 per stage: b / stride = umulhi(b, magic)
     int toff[LDS_MAX_FAC];         // offset of the stage's twiddles W_L^j, j < stride, in the LDS table
-    int ntw;                       // entries of that table (sum of the strides > 1)
+    int anch[LDS_MAX_FAC];         // twiddle tables of the stage (radix 8 / 16): 1 = W^j only,
+                                   // 2 = W^j, W^{4j}, 3 = W^{qj} for q = 1..4 (and 8, 12)
+    int ntw;                       // entries of that table (tables x strides > 1)
 };
 
 // middle-step constants of one bin pair (k, M - k), 48 bytes, built per slot on the host
@@ -101,11 +103,48 @@ __device__ __forceinline__ void dft_small(cpx (&x)[16]) {
 
 // One stage over the whole array.  L: block length of the stage, r: radix, stride = L / r.
 // Forward (DIF): butterfly, then output q times W_L^{j q}.  Inverse: input q times
-// conj(W_L^{j q}), then inverse butterfly.  Only W_L^j is read, from per-stage tables copied
-// into LDS once per workgroup; the other powers are products (depth <= 5 for radix 16).
+// conj(W_L^{j q}), then inverse butterfly.  The powers come from per-stage tables copied into
+// LDS once per workgroup.  A chain of products from W_L^j alone multiplies that entry's fp32
+// rounding error by q (up to 15 in a radix-16 stage: chi2 of 4096-sample traces was off by
+// up to 2.8e-5 relative), so radix-8 / 16 stages carry more tables where LDS permits
+// (lds_layout): T = 2 adds W^{4j} (error <= 3 + 3 entry roundings), T = 3 tabulates
+// q = 1..4 (and 8, 12): every power is one table entry or one product of two.
 template <int R>
-__device__ __forceinline__ void twiddle_powers(cpx (&w)[16], const cpx* tw1, int j) {
+__device__ __forceinline__ void twiddle_powers(cpx (&w)[16], const cpx* tw1, int j, int stride,
+                                               int T) {
     w[1] = tw1[j];
+    if constexpr (R >= 8) {
+        if (T >= 2) {
+            if (T == 3) {
+                w[2] = tw1[stride + j];
+                w[3] = tw1[2 * stride + j];
+                w[4] = tw1[3 * stride + j];
+            } else {
+                w[4] = tw1[stride + j];
+                w[2] = cmul(w[1], w[1]);
+                w[3] = cmul(w[2], w[1]);
+            }
+            w[5] = cmul(w[4], w[1]);
+            w[6] = cmul(w[4], w[2]);
+            w[7] = cmul(w[4], w[3]);
+            if constexpr (R > 8) {
+                if (T == 3) {
+                    w[8] = tw1[4 * stride + j];
+                    w[12] = tw1[5 * stride + j];
+                } else {
+                    w[8] = cmul(w[4], w[4]);
+                    w[12] = cmul(w[8], w[4]);
+                }
+                w[9] = cmul(w[8], w[1]);
+                w[10] = cmul(w[8], w[2]);
+                w[11] = cmul(w[8], w[3]);
+                w[13] = cmul(w[12], w[1]);
+                w[14] = cmul(w[12], w[2]);
+                w[15] = cmul(w[12], w[3]);
+            }
+            return;
+        }
+    }
     if constexpr (R > 2) w[2] = cmul(w[1], w[1]);
     if constexpr (R > 3) w[3] = cmul(w[2], w[1]);
     if constexpr (R > 4) {
@@ -130,7 +169,7 @@ __device__ __forceinline__ void twiddle_powers(cpx (&w)[16], const cpx* tw1, int
 
 template <int R, bool FWD>
 __device__ __forceinline__ void stage(cpx* z, const cpx* tw1, int M, int L,
-                                      unsigned magic) {
+                                      unsigned magic, int T) {
     const int stride = L / R;
     const int nbf = M / R;
     for (int b = threadIdx.x; b < nbf; b += blockDim.x) {
@@ -142,7 +181,7 @@ __device__ __forceinline__ void stage(cpx* z, const cpx* tw1, int M, int L,
 #pragma unroll
         for (int t = 0; t < R; ++t) x[t] = base[t * stride];
         const bool tw_needed = (stride > 1);          // last stage: every twiddle is 1
-        if (tw_needed) twiddle_powers<R>(w, tw1, j);
+        if (tw_needed) twiddle_powers<R>(w, tw1, j, stride, T);
         if constexpr (!FWD) {
             if (tw_needed) {
 #pragma unroll
@@ -165,17 +204,17 @@ __device__ __forceinline__ void stage(cpx* z, const cpx* tw1, int M, int L,
 // or without radix 8 and 16, needs far fewer registers and can run with 1024 threads)
 template <bool FWD, int MAXR = 16>
 __device__ __forceinline__ void stage_any(int r, cpx* z, const cpx* tw1, int M, int L,
-                                          unsigned magic) {
+                                          unsigned magic, int T) {
     if constexpr (MAXR >= 16) {
-        if (r == 16) { stage<16, FWD>(z, tw1, M, L, magic); return; }
+        if (r == 16) { stage<16, FWD>(z, tw1, M, L, magic, T); return; }
     }
     if constexpr (MAXR >= 8) {
-        if (r == 8) { stage<8, FWD>(z, tw1, M, L, magic); return; }
+        if (r == 8) { stage<8, FWD>(z, tw1, M, L, magic, T); return; }
     }
-    if (r == 5) stage<5, FWD>(z, tw1, M, L, magic);
-    else if (r == 4) stage<4, FWD>(z, tw1, M, L, magic);
-    else if (r == 3) stage<3, FWD>(z, tw1, M, L, magic);
-    else stage<2, FWD>(z, tw1, M, L, magic);
+    if (r == 5) stage<5, FWD>(z, tw1, M, L, magic, 1);
+    else if (r == 4) stage<4, FWD>(z, tw1, M, L, magic, 1);
+    else if (r == 3) stage<3, FWD>(z, tw1, M, L, magic, 1);
+    else stage<2, FWD>(z, tw1, M, L, magic, 1);
 }
 
 // position of frequency bin k in the digit-reversed output of the forward transform
@@ -227,7 +266,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
         if constexpr (FWD) {
             int L = M;
             for (int i = 0; i < g.nfac; ++i) {
-                stage_any<true, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                stage_any<true, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i], g.anch[i]);
                 L /= g.fac[i];
                 __syncthreads();
             }
@@ -239,7 +278,7 @@ __global__ __launch_bounds__(BT) void k_lds_fft(LdsGeom g, const float2* __restr
                 L /= g.fac[i];
             }
             for (int i = g.nfac - 1; i >= 0; --i) {
-                stage_any<false, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                stage_any<false, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i], g.anch[i]);
                 __syncthreads();
             }
         }
@@ -369,7 +408,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
             if (si == 0) {
                 int L = M;
                 for (int i = 0; i < g.nfac; ++i) {
-                    stage_any<true, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i]);
+                    stage_any<true, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, L, g.magic[i], g.anch[i]);
                     L /= g.fac[i];
                     __syncthreads();
                 }
@@ -453,7 +492,7 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     L /= g.fac[i];
                 }
                 for (int i = g.nfac - 1; i >= 0; --i) {
-                    stage_any<false, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i]);
+                    stage_any<false, MAXR>(g.fac[i], z, tw1 + g.toff[i], M, Ls[i], g.magic[i], g.anch[i]);
                     __syncthreads();
                 }
             }
@@ -544,18 +583,81 @@ bool factorize(int M, std::vector<int>* fac) {
     return rem == 1 && (int)fac->size() <= LDS_MAX_FAC;
 }
 
-int stage_twiddle_count(int M, const std::vector<int>& fac) {
+// tables of one stage: exponents q of the tabulated W_L^{q j}
+int anchor_list(int r, int T, int (&e)[6]) {
+    e[0] = 1;
+    if (r < 8 || T <= 1) return 1;
+    if (T == 2) { e[1] = 4; return 2; }
+    e[1] = 2; e[2] = 3; e[3] = 4;
+    if (r == 8) return 4;
+    e[4] = 8; e[5] = 12;
+    return 6;
+}
+
+int stage_twiddle_count(int M, const std::vector<int>& fac, int T = 1) {
     int L = M, n = 0;
     for (int r : fac) {
-        if (L / r > 1) n += L / r;
+        int e[6];
+        if (L / r > 1) n += anchor_list(r, T, e) * (L / r);
         L /= r;
     }
     return n;
 }
 
+// How many twiddle tables the radix-8 / 16 stages of a length-M transform get: the most
+// (3, then 2) that neither exceeds the LDS budget nor lowers the number of workgroups a CU
+// holds (other_bytes = everything else the kernel keeps in LDS besides data and twiddles).
+int choose_anchor_level(int M, const std::vector<int>& fac, size_t other_bytes) {
+    const size_t base = other_bytes + (size_t)M * 8;
+    const size_t b1 = base + (size_t)stage_twiddle_count(M, fac, 1) * 8;
+    for (int T = 3; T >= 2; --T) {
+        const size_t bt = base + (size_t)stage_twiddle_count(M, fac, T) * 8;
+        if (bt <= LDS_BUDGET && LDS_BUDGET / bt == LDS_BUDGET / b1) return T;
+    }
+    return 1;
+}
+
+// stage geometry and twiddle tables (host copy) of a factorisation
+void lds_layout(int M, const std::vector<int>& fac, int T, LdsGeom* g, std::vector<float2>* tab) {
+    memset(g, 0, sizeof(*g));
+    g->M = M;
+    g->N = 2 * M;
+    g->nfac = (int)fac.size();
+    int L = M;
+    for (int i = 0; i < g->nfac; ++i) {
+        g->fac[i] = fac[i];
+        const unsigned stride = (unsigned)(L / fac[i]);
+        g->magic[i] = (unsigned)((1ull << 32) / stride) + 1u;     // unused when stride == 1
+        g->toff[i] = g->ntw;
+        int e[6];
+        const int nt = anchor_list(fac[i], T, e);
+        g->anch[i] = (fac[i] >= 8) ? T : 1;
+        if (stride > 1) g->ntw += nt * (int)stride;
+        L /= fac[i];
+    }
+    if (!tab) return;
+    tab->assign((size_t)std::max(1, g->ntw), make_float2(0.f, 0.f));
+    L = M;
+    for (int i = 0; i < g->nfac; ++i) {
+        const int stride = L / g->fac[i];
+        int e[6];
+        const int nt = anchor_list(g->fac[i], T, e);
+        if (stride > 1)
+            for (int a = 0; a < nt; ++a)
+                for (int j = 0; j < stride; ++j) {
+                    const long long m = ((long long)j * e[a]) % L;                   // W_L^{e j}
+                    const double ang = -6.283185307179586476925286766559 * (double)m / (double)L;
+                    (*tab)[g->toff[i] + a * stride + j] =
+                        make_float2((float)std::cos(ang), (float)std::sin(ang));
+                }
+        L /= g->fac[i];
+    }
+}
+
+constexpr size_t LDS_OTHER_BYTES = (size_t)LDS_VLOW * 8 + 32 * 4 + 32 * sizeof(OfxCand);
 size_t lds_bytes_for(int M, const std::vector<int>& fac) {
-    return (size_t)M * 8 + (size_t)LDS_VLOW * 8 + (size_t)stage_twiddle_count(M, fac) * 8 +
-           32 * 4 + 32 * sizeof(OfxCand);
+    const int T = choose_anchor_level(M, fac, LDS_OTHER_BYTES);
+    return (size_t)M * 8 + LDS_OTHER_BYTES + (size_t)stage_twiddle_count(M, fac, T) * 8;
 }
 
 // no radix-16 stage: at most one more stage, but butterflies small enough for 1024 threads
@@ -663,39 +765,14 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
     LdsGeom g;
-    memset(&g, 0, sizeof(g));
-    g.M = M;
-    g.N = N;
-    g.nfac = (int)fac.size();
-    {
-        int L = M;
-        for (int i = 0; i < g.nfac; ++i) {
-            g.fac[i] = fac[i];
-            const unsigned stride = (unsigned)(L / fac[i]);
-            g.magic[i] = (unsigned)((1ull << 32) / stride) + 1u;     // unused when stride == 1
-            g.toff[i] = g.ntw;
-            if (stride > 1) g.ntw += (int)stride;
-            L /= fac[i];
-        }
-    }
+    std::vector<float2> t1;
+    lds_layout(M, fac, choose_anchor_level(M, fac, LDS_OTHER_BYTES), &g,
+               p->d_lds_tw ? nullptr : &t1);
     const double c0 = -6.283185307179586476925286766559 / (double)N;
     if (!p->d_lds_tw) {
-        // per-stage twiddles W_L^j, j < stride (stages with stride 1 have none)
-        std::vector<float2> t1((size_t)g.ntw);
-        int L = M;
-        for (int i = 0; i < g.nfac; ++i) {
-            const int stride = L / g.fac[i];
-            if (stride > 1)
-                for (int j = 0; j < stride; ++j) {
-                    const double a1 = c0 * 2.0 * (double)j * (double)(M / L);       // W_L^j
-                    t1[g.toff[i] + j] = make_float2((float)std::cos(a1), (float)std::sin(a1));
-                }
-            L /= g.fac[i];
-        }
-        OFX_HIP(hipMalloc(&p->d_lds_tw, sizeof(float2) * std::max<size_t>(1, t1.size())));
-        if (!t1.empty())
-            OFX_HIP(hipMemcpy(p->d_lds_tw, t1.data(), sizeof(float2) * t1.size(),
-                              hipMemcpyHostToDevice));
+        OFX_HIP(hipMalloc(&p->d_lds_tw, sizeof(float2) * t1.size()));
+        OFX_HIP(hipMemcpy(p->d_lds_tw, t1.data(), sizeof(float2) * t1.size(),
+                          hipMemcpyHostToDevice));
     }
     std::vector<LdsSlot> args;
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
@@ -837,34 +914,13 @@ int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
     const int M = n_complex;
     bool small = false;
     if (M < 8 || !choose_factors(M, 0, &fac, &small)) return OFX_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)M * 8 + (size_t)stage_twiddle_count(M, fac) * 8;
+    const int T = choose_anchor_level(M, fac, 0);
+    const size_t lds = (size_t)M * 8 + (size_t)stage_twiddle_count(M, fac, T) * 8;
     if (lds > LDS_BUDGET) return OFX_ERR_UNSUPPORTED;
     OfxLdsFft* f = new OfxLdsFft();
-    memset(&f->g, 0, sizeof(f->g));
-    f->g.M = M;
-    f->g.N = 2 * M;
-    f->g.nfac = (int)fac.size();
+    std::vector<float2> t1;
+    lds_layout(M, fac, T, &f->g, &t1);
     f->lds = lds;
-    int L = M;
-    for (int i = 0; i < f->g.nfac; ++i) {
-        f->g.fac[i] = fac[i];
-        const unsigned stride = (unsigned)(L / fac[i]);
-        f->g.magic[i] = (unsigned)((1ull << 32) / stride) + 1u;
-        f->g.toff[i] = f->g.ntw;
-        if (stride > 1) f->g.ntw += (int)stride;
-        L /= fac[i];
-    }
-    std::vector<float2> t1((size_t)std::max(1, f->g.ntw));
-    L = M;
-    for (int i = 0; i < f->g.nfac; ++i) {
-        const int stride = L / f->g.fac[i];
-        if (stride > 1)
-            for (int j = 0; j < stride; ++j) {
-                const double a1 = -6.283185307179586476925286766559 * (double)j / (double)L;
-                t1[f->g.toff[i] + j] = make_float2((float)std::cos(a1), (float)std::sin(a1));
-            }
-        L /= f->g.fac[i];
-    }
     std::vector<int> pos((size_t)M);
     for (int k = 0; k < M; ++k) pos[k] = pos_of(k, f->g);
     hipDeviceProp_t prop;

@@ -180,7 +180,10 @@ extern "C" int ofx_synth_traces_psd(float* traces, float* truth, long long n_tra
     const int CH = 2048;                                 // traces per FFT batch
     if (g_sfft.n != n_samples) {
         ofx_synth_release();
-        OFX_FFT(rocfft_setup());
+        {
+            const int rc_setup = ofx_rocfft_setup_once();
+            if (rc_setup) return rc_setup;
+        }
         size_t len = (size_t)n_samples;
         OFX_FFT(rocfft_plan_create(&g_sfft.c2r, rocfft_placement_notinplace,
                                    rocfft_transform_type_real_inverse, rocfft_precision_single,

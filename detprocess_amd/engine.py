@@ -293,3 +293,43 @@ def synth_traces(n_traces, n_samples, template, sigma, amp_lo, amp_hi,
                "ofx_synth_traces")
     torch.cuda.current_stream(dev).synchronize()   # t must outlive the kernel
     return out, truth
+
+
+class SynthSource:
+    """Device-side generator of the bench events (SURVEY.md section 8d recipe), keyed by
+    (seed, global event index): ``fill(lo, hi, buf)`` writes the events [lo, hi) into
+    buf[: hi - lo] on the current stream without a host synchronisation (the tables live as
+    long as the object), so it can run on a producer stream beside the hot path
+    (``detprocess_amd.dist.run_sharded``)."""
+
+    def __init__(self, n_samples, template, psd, fs, amp_lo, amp_hi, pulse_fraction=0.5,
+                 max_delay=2000, seed=0, device=0):
+        torch = _torch()
+        self._lib = _lib.load()
+        self.n_samples = int(n_samples)
+        self.device = torch.device("cuda", device)
+        self._t = torch.as_tensor(np.asarray(template, dtype=np.float32), device=self.device)
+        K = self.n_samples // 2 + 1
+        J1 = np.asarray(psd, dtype=np.float64)[:K]
+        self._namp = torch.as_tensor(
+            (np.sqrt(J1 * self.n_samples * float(fs) / 2.0) / self.n_samples).astype(np.float32),
+            device=self.device)
+        self._args = (float(amp_lo), float(amp_hi), float(pulse_fraction), int(max_delay),
+                      int(seed))
+
+    def fill(self, lo, hi, buf):
+        torch = _torch()
+        n = int(hi) - int(lo)
+        if n <= 0:
+            return
+        if buf.dtype != torch.float32 or not buf.is_contiguous() or buf.shape[0] < n:
+            raise ValueError("ERROR: SynthSource.fill needs a contiguous float32 buffer of at "
+                             "least hi - lo events")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        a_lo, a_hi, frac, dmax, seed = self._args
+        _lib.check(self._lib.ofx_synth_traces_psd(
+            buf.data_ptr(), None, n, int(lo), self.n_samples, self._t.data_ptr(),
+            self._namp.data_ptr(), a_lo, a_hi, frac, dmax, seed, C.c_void_p(stream)),
+            "ofx_synth_traces_psd")
+
+    __call__ = fill

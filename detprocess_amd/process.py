@@ -457,6 +457,45 @@ class FeatureProcessing:
             return cp.plan.process(tr, valid=valid)
         return self._collect(run, as_dataframe, traces=traces, valid=valid)
 
+    def plans(self, n_samples=None):
+        """{(channel, nb_samples, nb_pretrigger_samples): plan} of the compiled configuration
+        (compiles for ``n_samples`` first when given)."""
+        if n_samples is not None and (self._plans is None or self._compiled_n != n_samples
+                                      or getattr(self, "_compiled_streams", False)):
+            self._compile(int(n_samples))
+        return {k: cp.plan for k, cp in (self._plans or {}).items() if cp.plan is not None}
+
+    def device_columns(self):
+        """{plan key: [(column name, float offset in the plan's output row)]} -- the map from the
+        device-resident rows of ``process_device`` to the reference's column names."""
+        return {k: list(cp.columns) for k, cp in (self._plans or {}).items() if cp.plan is not None}
+
+    def process_device(self, traces, valid=None, outs=None):
+        """``process`` without the trip to the host: traces is a CUDA tensor [B, C, N]; every
+        channel plan is launched once on it and its float32 [B, row] output stays on the
+        device.  Returns {plan key: tensor}; ``outs`` (same keys) supplies preallocated outputs.
+        External (host-side) extractors and energyabsorbed's host finish are not run here."""
+        shape = tuple(traces.shape)
+        if len(shape) != 3 or shape[1] != len(self._channels):
+            raise ValueError(f"ERROR: traces must be [B, {len(self._channels)}, N]")
+        if (self._plans is None or self._compiled_n != shape[2]
+                or getattr(self, "_compiled_streams", False)):
+            self._compile(shape[2])
+        res = {}
+        for key, cp in self._plans.items():
+            if cp.plan is None:
+                continue
+            tr = traces
+            if (not getattr(cp, "nxm", False) and len(self._channels) == 1
+                    and cp.plan.n_channels == 1):
+                tr = traces.reshape(shape[0], shape[2])
+            if getattr(cp, "nxm", False):
+                res[key] = cp.plan.process(tr, valid=valid)
+            else:
+                res[key] = cp.plan.process(tr, valid=valid,
+                                           out=None if outs is None else outs.get(key))
+        return res
+
     def process_adc(self, adc, trigger_index, scale, offset, n_samples=None, as_dataframe=True):
         """Events cut on the GPU out of continuous raw-data streams (SURVEY.md 8f rank 2;
         processing_data.py:640-656, 674-684).  adc: int16 [C, n_stream] (C =

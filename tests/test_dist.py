@@ -1,7 +1,8 @@
 """N > 1 path on CPU: world_size-2 gloo.  Event ranges are sharded with no
 data-path collective; the only exchange is the final all-gather of the feature
 matrix.  The per-shard compute is stood in by the oracle
-here (tests may use it); the sharding / gather code is the product's."""
+here (tests may use it); the sharding / chunking / gather code is the product's:
+``detprocess_amd.dist.run_sharded``, the same function ``bench.py --gpus N`` drives."""
 import os
 import socket
 
@@ -33,10 +34,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, total, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _setup(total):
     from detprocess_amd import synth
     from oracle import of1x1 as orc
     n, fs, pre = 1024, 1.25e6, 512
@@ -44,24 +42,50 @@ def _worker(rank, world, port, total, q):
     psd = synth.make_psd(n, fs)
     filt = orc.OFFilter(tmpl, psd, fs, pre)
     traces, _, _ = synth.make_traces(total, tmpl, psd, fs, filt.ampres, seed=1, max_delay=100)
+
+    def source(lo, hi, buf):                       # events keyed by their global index
+        buf[: hi - lo] = torch.as_tensor(traces[lo:hi])
+
+    def process(events, out):
+        r = orc.process_events(filt, events.numpy(), "unconstrained")
+        out[:] = torch.tensor(np.stack([r["amp"], r["t0"], r["chi2"], r["lowchi2"]], axis=1))
+
+    return n, traces, source, process
+
+
+def _worker(rank, world, port, total, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, traces, source, process = _setup(total)
     lo, hi = ofdist.shard_range(total, rank, world)
-    r = orc.process_events(filt, traces[lo:hi], "unconstrained")
-    local = torch.tensor(np.stack([r["amp"], r["t0"], r["chi2"], r["lowchi2"]], axis=1))
-    full = ofdist.gather_features(local, total, rank, world)
+    mk = lambda: torch.empty((hi - lo, 4), dtype=torch.float64)     # (fp64: the oracle's rows)
+    full = ofdist.run_sharded(total, chunk, source, process, 4, (n,), rank=rank, world=world,
+                              dtype=torch.float64, out=mk())
+    # the resident form of the same call (this rank's shard already in memory)
+    full2 = ofdist.run_sharded(total, chunk, torch.as_tensor(traces[lo:hi]), process, 4, (n,),
+                               rank=rank, world=world, out=mk())
+    assert torch.equal(full, full2)
     if rank == 0:
         q.put(full.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [37, 64])
-def test_two_rank_gloo_equals_single_process(total):
+def test_chunk_spans():
+    assert ofdist.chunk_spans(3, 3, 5) == []
+    assert ofdist.chunk_spans(3, 14, 5) == [(3, 8), (8, 13), (13, 14)]
+    assert ofdist.chunk_spans(0, 10, 10) == [(0, 10)]
+
+
+@pytest.mark.parametrize("total,chunk", [(37, 7), (64, 32), (5, 100)])
+def test_two_rank_gloo_equals_single_process(total, chunk):
     from detprocess_amd import synth
     from oracle import of1x1 as orc
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, chunk, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=180)

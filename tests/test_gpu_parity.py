@@ -232,7 +232,7 @@ def test_fused_handles_wide_lowchi2_and_bands():
             # algorithms.py:1013-1038 on one-sided bins [lo, hi): sqrt(2 |FFT/N|^2 N / fs), averaged
             V = np.fft.rfft(x64, axis=-1)[:, lo:hi_] / n
             want = np.sqrt(2.0 * np.abs(V) ** 2 * n / FS).mean(axis=-1)
-            assert np.allclose(out[:, plan.band_offset(bid)], want, rtol=2e-5), (engine, lo, hi_)
+            assert np.allclose(out[:, plan.band_offset(bid)], want, rtol=1e-5), (engine, lo, hi_)
         plan.close()
     # the same on a three-slot plan (the stash is written once, by the first slot's pass)
     plan, ft, filt, tmpl, psd = _mk(n, engine="fused")
@@ -308,7 +308,7 @@ def test_edge_cases(engine):
     assert np.array_equal(out[2:, o + 7].astype(int), ref["index"][2:])
     assert abs(out[1, o + 0]) < 1e-3 * ft.ampres                                 # DC only
     assert out[3, o + 7] == n // 2 - 4000
-    assert np.allclose(out[2:, o + 0], ref["amp"][2:], rtol=2e-5, atol=1e-4 * ft.ampres)
+    assert np.allclose(out[2:, o + 0], ref["amp"][2:], rtol=1e-5, atol=1e-4 * ft.ampres)
     # invalid rows
     valid = torch.tensor([1, 0, 1, 0, 1], dtype=torch.uint8, device="cuda:0")
     out2 = plan.process(torch.as_tensor(x, device="cuda:0"), valid=valid).cpu().numpy()

@@ -210,9 +210,9 @@ def test_feature_extractors_static_methods():
     assert set(r) == {f"{q}_myof" for q in ("amp", "t0", "chi2", "lowchi2", "chi2nopulse",
                                             "ampres", "timeres")}
     assert isinstance(r["amp_myof"], float)
-    assert r["amp_myof"] == pytest.approx(ref["amp"], rel=2e-5, abs=1e-4 * filt.ampres)
+    assert r["amp_myof"] == pytest.approx(ref["amp"], rel=1e-5, abs=1e-4 * filt.ampres)
     assert r["t0_myof"] == pytest.approx(ref["t0"], rel=1e-6, abs=1e-12)
-    assert r["chi2_myof"] == pytest.approx(ref["chi2"], rel=2e-5, abs=2e-6 * ref["chi2nopulse"])
+    assert r["chi2_myof"] == pytest.approx(ref["chi2"], rel=1e-5, abs=2e-6 * ref["chi2nopulse"])
     assert r["ampres_myof"] == pytest.approx(filt.ampres, rel=1e-6)
     # batch -> arrays
     ob.clear_signal()
@@ -220,14 +220,14 @@ def test_feature_extractors_static_methods():
     ob.update_signal("chanA", x32)
     r = FE.of1x1_nodelay("chanA", ob, template_tag="default", lowchi2_fcutoff=15000)
     refn = orc.process_events(filt, x32.astype(np.float64), "nodelay", lowchi2_fcutoff=15000)
-    assert np.allclose(r["amp_of1x1_nodelay"], refn["amp"], rtol=2e-5, atol=1e-4 * filt.ampres)
-    assert np.allclose(r["lowchi2_of1x1_nodelay"], refn["lowchi2"], rtol=2e-5, atol=1e-2)
+    assert np.allclose(r["amp_of1x1_nodelay"], refn["amp"], rtol=1e-5, atol=1e-4 * filt.ampres)
+    assert np.allclose(r["lowchi2_of1x1_nodelay"], refn["lowchi2"], rtol=1e-5, atol=1e-2)
     assert "t0_of1x1_nodelay" not in r                      # algorithms.py:344-348
     # interpolate=True (algorithms.py:357): refined t0 within half a bin of the discrete one
     ri = FE.of1x1_unconstrained("chanA", ob, template_tag="default", interpolate=True)
     refi = orc.process_events(filt, x32.astype(np.float64), "unconstrained", interpolate=True)
     assert np.allclose(ri["t0_of1x1_unconstrained"], refi["t0"], rtol=0, atol=1e-3 / FS)
-    assert np.allclose(ri["amp_of1x1_unconstrained"], refi["amp"], rtol=2e-5,
+    assert np.allclose(ri["amp_of1x1_unconstrained"], refi["amp"], rtol=1e-5,
                        atol=1e-4 * filt.ampres)
     # trace family
     tr = x32[1]
@@ -272,21 +272,21 @@ def test_feature_processing_batch_driver(engine):
     r = orc.process_events(filt, x, "unconstrained")
     assert np.array_equal(np.round(df["t0_of1x1_unconstrained_Melange1pc1ch"][ok] * FS),
                           (r["index"] - pre)[ok])
-    assert np.allclose(df["amp_of1x1_unconstrained_Melange1pc1ch"][ok], r["amp"][ok], rtol=2e-5,
+    assert np.allclose(df["amp_of1x1_unconstrained_Melange1pc1ch"][ok], r["amp"][ok], rtol=1e-5,
                        atol=1e-4 * filt.ampres)
     rc = orc.process_events(filt, x, "constrained", window_min_from_trig_usec=-400,
                             window_max_from_trig_usec=400)
-    assert np.allclose(df["amp_of1x1_constrained_Melange1pc1ch"][ok], rc["amp"][ok], rtol=2e-5,
+    assert np.allclose(df["amp_of1x1_constrained_Melange1pc1ch"][ok], rc["amp"][ok], rtol=1e-5,
                        atol=1e-4 * filt.ampres)
     rn = orc.process_events(filt, x, "nodelay", lowchi2_fcutoff=15000)
     assert np.allclose(df["lowchi2_of1x1_nodelay_Melange1pc1ch"][ok], rn["lowchi2"][ok],
-                       rtol=2e-5, atol=2e-6 * r["chi2nopulse"][ok].max())
+                       rtol=1e-5, atol=2e-6 * r["chi2nopulse"][ok].max())
     ri = orc.process_events(filt, x, "unconstrained", interpolate=True)
     assert np.allclose(df["t0_of1x1_interp_Melange1pc1ch"][ok], ri["t0"][ok], rtol=0, atol=1e-3 / FS)
-    assert np.allclose(df["chi2_of1x1_interp_Melange1pc1ch"][ok], ri["chi2"][ok], rtol=2e-5,
+    assert np.allclose(df["chi2_of1x1_interp_Melange1pc1ch"][ok], ri["chi2"][ok], rtol=1e-5,
                        atol=2e-6 * r["chi2nopulse"][ok].max())
     rg = orc.process_events(filt_g, x, "unconstrained")
-    assert np.allclose(df["amp_of1x1_glitch_Melange1pc1ch"][ok], rg["amp"][ok], rtol=2e-5,
+    assert np.allclose(df["amp_of1x1_glitch_Melange1pc1ch"][ok], rg["amp"][ok], rtol=1e-5,
                        atol=1e-4 * filt_g.ampres)
     # trace features with the reference's window arithmetic and end-exclusive slices
     lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_start_usec=0,
@@ -484,11 +484,11 @@ def test_example_shaped_config_at_25000_samples():
     assert not any("of1x2x2" in c for c in df.columns)
     x0 = ev[:, 0, :].astype(np.float64)
     rn = orc.process_events(filt, x0, "nodelay")
-    assert np.allclose(df["amp_of1x1_nodelay_Melange1pc1ch"], rn["amp"], rtol=2e-5, atol=1e-4 * filt.ampres)
+    assert np.allclose(df["amp_of1x1_nodelay_Melange1pc1ch"], rn["amp"], rtol=1e-5, atol=1e-4 * filt.ampres)
     rc = orc.process_events(filt, x0, "constrained", window_min_from_trig_usec=-400,
                             window_max_from_trig_usec=400)
     assert np.array_equal(np.round(df["t0_of1x1_constrained_Melange1pc1ch"] * FS), rc["index"] - pre)
-    assert np.allclose(df["chi2_of1x1_constrained_Melange1pc1ch"], rc["chi2"], rtol=2e-5,
+    assert np.allclose(df["chi2_of1x1_constrained_Melange1pc1ch"], rc["chi2"], rtol=1e-5,
                        atol=2e-6 * rc["chi2nopulse"].max())
     for j, ch in ((1, "Melange025pcLeft"), (2, "Melange025pcRight")):
         ri = orc.process_events(filt, ev[:, j, :].astype(np.float64), "unconstrained", interpolate=True)
@@ -596,7 +596,7 @@ def test_psd_amp_and_energyabsorbed(engine):
     wb, ww = plan.add_tdwindow(0, 16000), plan.add_tdwindow(16000, 20000)
     out = plan.process(torch.as_tensor(x32, device="cuda:0")).cpu().numpy().astype(np.float64)
     for i, name in zip(ids, names):
-        assert np.allclose(out[:, plan.band_offset(i)], want[name], rtol=2e-5), name
+        assert np.allclose(out[:, plan.band_offset(i)], want[name], rtol=1e-5), name
     o = plan.tdwindow_offset(ww)
     assert np.allclose(out[:, o + 4], x64[:, 16000:20000].sum(axis=1), rtol=2e-6)
     assert np.allclose(out[:, o + 5], (x64[:, 16000:20000] ** 2).sum(axis=1), rtol=2e-6)
@@ -611,7 +611,7 @@ def test_psd_amp_and_energyabsorbed(engine):
     r = FE.psd_amp("A", ob, f_lims=f_lims)
     assert set(r) == {f"psd_amp_{nm}" for nm in names}
     for nm in names:
-        assert np.allclose(r[f"psd_amp_{nm}"], want[nm], rtol=2e-5)
+        assert np.allclose(r[f"psd_amp_{nm}"], want[nm], rtol=1e-5)
     with pytest.raises(ValueError):
         FE.psd_amp("A", ob)
     # batched driver with the reference's YAML keys
@@ -637,8 +637,8 @@ A:
     fp = FeatureProcessing(yaml_txt, fdA, ["A"], FS, nb_samples=n, nb_pretrigger_samples=pre,
                            engine=engine if engine == "rocfft" else "auto")
     df = fp.process(x32)
-    assert np.allclose(df["psd_amp_45_75_A"], want["45_75"], rtol=2e-5)
-    assert np.allclose(df["psd_amp_3000_9000_A"], want["3000_9000"], rtol=2e-5)
+    assert np.allclose(df["psd_amp_45_75_A"], want["45_75"], rtol=1e-5)
+    assert np.allclose(df["psd_amp_3000_9000_A"], want["3000_9000"], rtol=1e-5)
     lo, hi = orc.get_window_indices(n, pre, FS, window_min_from_trig_usec=-100,
                                     window_max_from_trig_usec=1000)
     e_ref = orc.energyabsorbed(x64, FS, 190.6e-9, 88e-9, 8.8e-3, lo, hi)

@@ -8,13 +8,17 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # ---- tolerances (north_star: within 1e-5 relative of the fp64 path) ----------
-# amp      : |d| <= 2e-5 |amp| + 1e-4 ampres       (fp32 FFT rounding ~1e-6 of the norm)
-# chi2     : |d| <= 2e-5 chi2 + 2e-6 chi2nopulse   (chi2 = chi0 - A^2 norm cancels at high SNR)
-# lowchi2  : |d| <= 2e-5 lowchi2 + 2e-6 chi2nopulse
+# amp      : |d| <= 1e-5 |amp| + 1e-4 ampres       (fp32 FFT rounding: ~5e-7 of the largest
+#            amplitude in the trace, so a noise-only event next to nothing is bounded in
+#            units of the resolution, not of itself)
+# chi2     : |d| <= 1e-5 chi2 + 2e-6 chi2nopulse   (chi2 = chi0 - A^2 norm: a pulse of SNR s in
+#            a trace of N samples cancels (s^2 + N) / N digits-worth; the absolute term is the
+#            fp32 error of the two terms that cancel)
+# lowchi2  : |d| <= 1e-5 lowchi2 + 2e-6 chi2nopulse
 # t0       : the BIN must match exactly; the float value to 1e-6 relative
 # timeres  : 2e-5 relative plus the relative error allowed on amp ; ampres 1e-6 relative
-AMP_RTOL, AMP_ATOL_SIGMA = 2e-5, 1e-4
-CHI_RTOL, CHI_ATOL_CHI0 = 2e-5, 2e-6
+AMP_RTOL, AMP_ATOL_SIGMA = 1e-5, 1e-4
+CHI_RTOL, CHI_ATOL_CHI0 = 1e-5, 2e-6
 
 
 def load_golden(name):
