@@ -140,6 +140,19 @@ def _cpu_worker(args):
     return done, time.perf_counter() - t0
 
 
+def _usable_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box shows every host core in the mask but grants a share of them)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(config, seconds=8.0):
     """The oracle (fp64 NumPy restatement of the detprocess+QETpy per-event path) timed on
     this host on a bounded sample of the same workload: `value` = 1
@@ -153,7 +166,7 @@ def cpu_baseline(config, seconds=8.0):
            "sample": f"{done} traces x {N_SAMPLES} samples, per-event loop of oracle/of1x1.py "
                      f"(fp64 NumPy FFTs, 1 thread), {el:.1f} s; workload of --config {config}"
                      + (" (one channel, one template tag of it)" if config == 3 else "")}
-    ncores = len(os.sched_getaffinity(0))
+    ncores = _usable_cores()
     try:
         with mp.get_context("spawn").Pool(ncores) as pool:
             res = pool.map(_cpu_worker, [(seconds, config, 200 + i) for i in range(ncores)])

@@ -57,6 +57,12 @@ _SYMBOLS = [
     ("ofx_trigger_get_traces", C.c_int, [_p, _p, _p, C.c_int, _p]),
     ("ofx_trigger_find", C.c_int, [_p, C.c_double, C.c_longlong, _p, _p, _p, C.c_longlong,
                                    C.POINTER(C.c_longlong), _p]),
+    ("ofx_trigger_above", C.c_int, [_p, C.c_double, _p, _p, C.c_longlong,
+                                    C.POINTER(C.c_longlong), _p]),
+    ("ofx_trigger_gather", C.c_int, [_p, _p, C.c_longlong, _p, _p, _p]),
+    ("ofx_trigger_set_pulse_table", C.c_int, [_p, _p]),
+    ("ofx_trigger_residual_subtract", C.c_int, [_p, _p, C.c_longlong, _p]),
+    ("ofx_trigger_residual_restore", C.c_int, [_p, _p, C.c_int, _p]),
     ("ofx_nxm_create", C.c_int, [C.POINTER(_p), C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                  C.c_int, C.c_int]),
     ("ofx_nxm_destroy", C.c_int, [_p]),

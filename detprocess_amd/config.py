@@ -31,20 +31,21 @@ OBSOLETE_KEYS = {          # config.py:71-79
 
 
 class _UniqueKeyLoader(SafeLoader):
-    """PyYAML silently keeps the last duplicate key; the reference refuses."""
+    """PyYAML silently keeps the last duplicate key; the reference refuses
+    (config.py:666-684).  The stock constructor builds the mapping; a mapping that came out
+    with fewer keys than the node has entries had a duplicate, which is then named."""
 
     def construct_mapping(self, node, deep=False):
-        if not isinstance(node, yaml.MappingNode):
-            raise yaml.constructor.ConstructorError(
-                None, None, f"expected a mapping node, but found {node.id}", node.start_mark)
-        mapping = {}
-        for key_node, value_node in node.value:
-            key = self.construct_object(key_node, deep=deep)
-            if key in mapping:
-                raise ValueError(f'ERROR: Duplicate key "{key}" found in the yaml file for '
-                                 f'same channel and algorithm. This is not allowed to '
-                                 f'avoid unwanted configuration!')
-            mapping[key] = self.construct_object(value_node, deep=deep)
+        mapping = super().construct_mapping(node, deep=deep)
+        if len(mapping) != len(node.value):
+            seen = set()
+            for key_node, _ in node.value:
+                key = self.construct_object(key_node, deep=True)
+                if key in seen:
+                    raise ValueError(f'ERROR: Duplicate key "{key}" found in the yaml file for '
+                                     f'same channel and algorithm. This is not allowed to '
+                                     f'avoid unwanted configuration!')
+                seen.add(key)
         return mapping
 
 

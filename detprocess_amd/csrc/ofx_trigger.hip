@@ -44,6 +44,11 @@ struct ofx_trigger {
     rocfft_execution_info info = nullptr;
     void* d_work = nullptr; size_t work_bytes = 0;
     long long plan_nblk = 0;
+    // residual pass (oftrigger.py:752-845)
+    float* d_dchi_saved = nullptr; size_t saved_elems = 0; bool saved = false;
+    float* d_pulse = nullptr;             // [M][M][N] delta-chi2 pulse-shape table G
+    long long* d_sel = nullptr; size_t sel_elems = 0;    // compaction / trigger-index staging
+    float* d_selv = nullptr;  size_t selv_elems = 0;
 };
 
 namespace {
@@ -376,7 +381,8 @@ extern "C" int ofx_trigger_destroy(ofx_trigger* t) {
     if (t->info) rocfft_execution_info_destroy(t->info);
     void* bufs[] = {t->d_hfft, t->d_xpad, t->d_spec, t->d_yblk, t->d_filt, t->d_dchi, t->d_scan,
                     t->d_key, t->d_tmp, t->d_stage, t->d_count, t->d_oidx, t->d_odchi, t->d_oamp,
-                    t->d_work, t->d_acc, t->d_vtd};
+                    t->d_work, t->d_acc, t->d_vtd, t->d_dchi_saved, t->d_pulse, t->d_sel,
+                    t->d_selv};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete t;
@@ -468,6 +474,7 @@ extern "C" int ofx_trigger_update_traces(ofx_trigger* t, const void* x, int dtyp
     }
     OFX_HIP(hipGetLastError());
     t->n = n;
+    t->saved = false;
     t->nblk = nblk;
     return OFX_OK;
 }
@@ -578,5 +585,212 @@ extern "C" int ofx_trigger_find(ofx_trigger* t, double chi2_threshold, long long
         ofx_set_error("ofx_trigger_find: %lld triggers found, capacity %lld", cnt, cap);
         return OFX_ERR_ARG;
     }
+    return OFX_OK;
+}
+
+
+// ------------------------------------------------------------------------------------
+// Pieces of find_triggers_once(dynamic=True) and find_triggers(residual=True)
+// (oftrigger.py:78-143, 752-845, 982-986).  The dynamic pile-up window is a user-supplied
+// Python function of the running range maximum, so the segmentation itself runs on the host
+// over the compacted list of above-threshold samples produced here.
+// ------------------------------------------------------------------------------------
+namespace {
+
+struct AboveThr {
+    const float* d;
+    float thr;
+    __host__ __device__ bool operator()(const long long& i) const { return d[i] > thr; }
+};
+
+__global__ void k_gather(const float* __restrict__ filt, const float* __restrict__ dchi,
+                         const long long* __restrict__ idx, long long m, long long n, int M,
+                         float* __restrict__ oamp, float* __restrict__ odchi) {
+    const long long i = (long long)blockIdx.x * TB + threadIdx.x;
+    if (i >= m) return;
+    const long long j = idx[i];
+    const bool in = j >= 0 && j < n;
+    if (odchi) odchi[i] = in ? dchi[j] : 0.0f;
+    for (int a = 0; a < M; ++a) oamp[i * M + a] = in ? filt[(size_t)a * n + j] : 0.0f;
+}
+
+// One workgroup per trigger: pulse[z] = sum_ab A_a A_b G_ab[z] with A = filtered[:, ti]
+// (the delta-chi2 trace of the best-fit pulse), j = first arg-max of it, then
+// dchi[ti - j + z] -= pulse[z]   (oftrigger.py:788-815).  Overlapping pulses of
+// neighbouring triggers meet in atomic adds.
+__global__ __launch_bounds__(TB) void k_residual(const float* __restrict__ filt,
+                                                 float* __restrict__ dchi,
+                                                 const float* __restrict__ G,
+                                                 const long long* __restrict__ trig, long long n,
+                                                 int N, int M) {
+    __shared__ unsigned long long best;
+    const long long ti = trig[blockIdx.x];
+    if (ti < 0 || ti >= n) return;
+    float A[TRIG_MAX];
+    for (int a = 0; a < M; ++a) A[a] = filt[(size_t)a * n + ti];
+    auto pulse = [&](int z) {
+        float p = 0.0f;
+        for (int a = 0; a < M; ++a)
+            for (int b = 0; b < M; ++b) p = fmaf(A[a] * A[b], G[((size_t)a * M + b) * N + z], p);
+        return p;
+    };
+    if (threadIdx.x == 0) best = 0ull;
+    __syncthreads();
+    unsigned long long k = 0ull;
+    for (int z = threadIdx.x; z < N; z += TB) {
+        const float p = pulse(z);
+        // order-preserving key of a float (pulses may dip below zero between lobes)
+        unsigned u = __float_as_uint(p);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        const unsigned long long c = ((unsigned long long)u << 32) |
+                                     (unsigned long long)(0xFFFFFFFFu - (unsigned)z);
+        k = c > k ? c : k;
+    }
+    atomicMax(&best, k);
+    __syncthreads();
+    const long long j = (long long)(0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull));
+    const long long start = ti - j;
+    for (int z = threadIdx.x; z < N; z += TB) {
+        const long long pos = start + z;
+        if (pos >= 0 && pos < n) atomicAdd(&dchi[pos], -pulse(z));
+    }
+}
+
+}  // namespace
+
+extern "C" int ofx_trigger_above(ofx_trigger* t, double chi2_threshold, long long* index,
+                                 float* dchi_out, long long cap, long long* n_out, void* stream) {
+    if (!t || t->n == 0) {
+        ofx_set_error("ofx_trigger_above: no trace (call ofx_trigger_update_trace first)");
+        return OFX_ERR_STATE;
+    }
+    if (!n_out || cap < 0 || (cap > 0 && (!index || !dchi_out))) {
+        ofx_set_error("ofx_trigger_above: bad argument");
+        return OFX_ERR_ARG;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = t->n;
+    int rc;
+    if ((rc = grow(&t->d_sel, &t->sel_elems, (size_t)n))) return rc;
+    AboveThr pred{t->d_dchi, (float)chi2_threshold};
+    hipcub::CountingInputIterator<long long> it(0);
+    size_t need = 0;
+    OFX_HIP(hipcub::DeviceSelect::If(nullptr, need, it, t->d_sel, t->d_count, (int)n, pred, st));
+    if (need > t->tmp_bytes) {
+        if (t->d_tmp) (void)hipFree(t->d_tmp);
+        t->d_tmp = nullptr;
+        t->tmp_bytes = 0;
+        OFX_HIP(hipMalloc(&t->d_tmp, need));
+        t->tmp_bytes = need;
+    }
+    size_t tb = t->tmp_bytes;
+    OFX_HIP(hipcub::DeviceSelect::If(t->d_tmp, tb, it, t->d_sel, t->d_count, (int)n, pred, st));
+    long long cnt = 0;
+    OFX_HIP(hipMemcpyAsync(&cnt, t->d_count, sizeof(long long), hipMemcpyDeviceToHost, st));
+    OFX_HIP(hipStreamSynchronize(st));
+    *n_out = cnt;
+    const long long m = std::min(cnt, cap);
+    if (m > 0) {
+        if ((rc = grow(&t->d_selv, &t->selv_elems, (size_t)m))) return rc;
+        hipLaunchKernelGGL(k_gather, dim3(blocks_for(m)), dim3(TB), 0, st, t->d_filt, t->d_dchi,
+                           t->d_sel, m, n, 0, (float*)nullptr, t->d_selv);
+        OFX_HIP(hipMemcpyAsync(index, t->d_sel, (size_t)m * sizeof(long long),
+                               hipMemcpyDeviceToHost, st));
+        OFX_HIP(hipMemcpyAsync(dchi_out, t->d_selv, (size_t)m * sizeof(float),
+                               hipMemcpyDeviceToHost, st));
+        OFX_HIP(hipStreamSynchronize(st));
+    }
+    if (cnt > cap) {
+        ofx_set_error("ofx_trigger_above: %lld samples above threshold, capacity %lld", cnt, cap);
+        return OFX_ERR_ARG;
+    }
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_gather(ofx_trigger* t, const long long* index, long long m,
+                                  float* amplitude, float* delta_chi2, void* stream) {
+    if (!t || t->n == 0 || m < 0 || (m > 0 && (!index || !amplitude))) {
+        ofx_set_error("ofx_trigger_gather: bad argument / no trace");
+        return OFX_ERR_ARG;
+    }
+    if (m == 0) return OFX_OK;
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = grow(&t->d_sel, &t->sel_elems, (size_t)m))) return rc;
+    if ((rc = grow(&t->d_selv, &t->selv_elems, (size_t)m * (t->M + 1)))) return rc;
+    OFX_HIP(hipMemcpyAsync(t->d_sel, index, (size_t)m * sizeof(long long), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_gather, dim3(blocks_for(m)), dim3(TB), 0, st, t->d_filt, t->d_dchi,
+                       t->d_sel, m, t->n, t->M, t->d_selv, t->d_selv + (size_t)m * t->M);
+    OFX_HIP(hipMemcpyAsync(amplitude, t->d_selv, (size_t)m * t->M * sizeof(float),
+                           hipMemcpyDeviceToHost, st));
+    if (delta_chi2)
+        OFX_HIP(hipMemcpyAsync(delta_chi2, t->d_selv + (size_t)m * t->M, (size_t)m * sizeof(float),
+                               hipMemcpyDeviceToHost, st));
+    OFX_HIP(hipStreamSynchronize(st));
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_set_pulse_table(ofx_trigger* t, const double* G) {
+    if (!t || !G) {
+        ofx_set_error("ofx_trigger_set_pulse_table: bad argument");
+        return OFX_ERR_ARG;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    const size_t cnt = (size_t)t->M * t->M * t->N;
+    std::vector<float> g(cnt);
+    for (size_t i = 0; i < cnt; ++i) g[i] = (float)G[i];
+    if (!t->d_pulse) OFX_HIP(hipMalloc(&t->d_pulse, cnt * sizeof(float)));
+    OFX_HIP(hipMemcpy(t->d_pulse, g.data(), cnt * sizeof(float), hipMemcpyHostToDevice));
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_residual_subtract(ofx_trigger* t, const long long* trigger_index,
+                                             long long m, void* stream) {
+    if (!t || t->n == 0 || m < 0 || (m > 0 && !trigger_index)) {
+        ofx_set_error("ofx_trigger_residual_subtract: bad argument / no trace");
+        return OFX_ERR_ARG;
+    }
+    if (!t->d_pulse) {
+        ofx_set_error("ofx_trigger_residual_subtract: no pulse table (ofx_trigger_set_pulse_table)");
+        return OFX_ERR_STATE;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (!t->saved) {                    // keep the first-pass trace (oftrigger.py:771, 826-828)
+        if ((rc = grow(&t->d_dchi_saved, &t->saved_elems, (size_t)t->n))) return rc;
+        OFX_HIP(hipMemcpyAsync(t->d_dchi_saved, t->d_dchi, (size_t)t->n * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+        t->saved = true;
+    }
+    if (m == 0) return OFX_OK;
+    if ((rc = grow(&t->d_sel, &t->sel_elems, (size_t)m))) return rc;
+    OFX_HIP(hipMemcpyAsync(t->d_sel, trigger_index, (size_t)m * sizeof(long long),
+                           hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_residual, dim3((unsigned)m), dim3(TB), 0, st, t->d_filt, t->d_dchi,
+                       t->d_pulse, t->d_sel, t->n, t->N, t->M);
+    OFX_HIP(hipGetLastError());
+    OFX_HIP(hipStreamSynchronize(st));
+    return OFX_OK;
+}
+
+extern "C" int ofx_trigger_residual_restore(ofx_trigger* t, float* residual_delta_chi2, int mem,
+                                            void* stream) {
+    if (!t || t->n == 0 || !t->saved) {
+        ofx_set_error("ofx_trigger_residual_restore: nothing saved");
+        return OFX_ERR_STATE;
+    }
+    OFX_HIP(hipSetDevice(t->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (residual_delta_chi2)
+        OFX_HIP(hipMemcpyAsync(residual_delta_chi2, t->d_dchi, (size_t)t->n * sizeof(float),
+                               mem == OFX_MEM_HOST ? hipMemcpyDeviceToHost
+                                                   : hipMemcpyDeviceToDevice, st));
+    OFX_HIP(hipMemcpyAsync(t->d_dchi, t->d_dchi_saved, (size_t)t->n * sizeof(float),
+                           hipMemcpyDeviceToDevice, st));
+    OFX_HIP(hipStreamSynchronize(st));
+    t->saved = false;
     return OFX_OK;
 }

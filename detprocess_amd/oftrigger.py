@@ -1,11 +1,17 @@
-"""OptimumFilterTrigger: continuous-data optimal-filter trigger on the GPU, one channel x one
-amplitude -- the interface of detprocess/core/oftrigger.py:336-1035 for that case
-(SURVEY.md section 8f rank 3).
+"""OptimumFilterTrigger: continuous-data optimal-filter trigger on the GPU -- the interface of
+detprocess/core/oftrigger.py:336-1035, N channels x M amplitudes.
 
 The one-time filter precompute (oftrigger.py:466-496, QETpy ``OFBase`` phi / weight /
 iweight) stays on the host in fp64; ``update_trace`` (FIR filtering of the whole stream, delta
-chi2, edge padding) and the threshold / range-merging / arg-max core of ``find_triggers_once``
-run in HIP through ``ofx_trigger_*`` (include/ofx.h).  There is no CPU fallback.
+chi2, edge padding), the threshold / range-merging / arg-max core of ``find_triggers_once``
+and the pulse subtraction of the residual pass run in HIP through ``ofx_trigger_*``
+(include/ofx.h).  There is no CPU fallback.
+
+Two steps are driven from the host because their inputs are host objects: the dynamic
+pile-up window is a user-supplied Python function of the running range maximum
+(oftrigger.py:78-143), so the device compacts the above-threshold samples and the ranges are
+cut here; and the saturation veto of the residual pass (oftrigger.py:772-786) low-passes
+the raw trace around each first-pass trigger only (a few hundred windows, not the stream).
 """
 
 import ctypes as C
@@ -15,6 +21,44 @@ import numpy as np
 
 from . import _lib
 from .filters import apply_coupling_and_notches, build_filter
+
+
+def _dynamic_ranges(x, amplitudes, threshold_function):
+    """Ranges [start, end) of the above-threshold samples x (ascending stream indices) for a
+    pile-up window that depends on the largest delta chi2 seen so far in the current range
+    (oftrigger.py:78-143): sample i opens a new range when x[i] - x[i-1] exceeds
+    threshold_function(max(amplitudes[start .. i])).  One pass with a running maximum; the
+    function is called again only when that maximum has changed."""
+    n = len(x)
+    if n == 0:
+        return []
+    cuts = [0]
+    run_max, window = amplitudes[0], None
+    for i in range(1, n):
+        if amplitudes[i] > run_max:
+            run_max, window = amplitudes[i], None
+        if window is None:
+            window = threshold_function(run_max)
+        if (x[i] - x[i - 1]) > window:
+            cuts.append(i)
+            run_max, window = amplitudes[i], None
+    return list(zip(cuts, cuts[1:] + [n]))
+
+
+def _lowpass_50khz_window(raw, fs, start, stop, pad=1024):
+    """qp.utils.lowpassfilter(trace, cut_off_freq=50e3, fs) -- first-order Butterworth run
+    forward and backward (filtfilt, even padding) -- evaluated on raw[start:stop] from a
+    window extended by ``pad`` samples on both sides: the filter's memory (pole 0.78 at 50 kHz /
+    1.25 MHz) is gone after a few dozen samples, so this equals the whole-stream result of
+    oftrigger.py:627-633 to rounding, at the cost of the windows actually looked at."""
+    from scipy.signal import butter, filtfilt
+    n = raw.shape[-1]
+    a0, a1 = max(0, start - pad), min(n, stop + pad)
+    seg = np.asarray(raw[a0:a1], dtype=np.float64)
+    b, a = butter(1, 50e3 / (0.5 * fs))
+    if seg.shape[-1] <= 9:
+        return seg[start - a0: stop - a0]
+    return filtfilt(b, a, seg, padtype="even")[start - a0: stop - a0]
 
 
 def _chi2_threshold(thresh, m_amplitudes=1):
@@ -210,17 +254,22 @@ class OptimumFilterTrigger:
             import torch
             torch.cuda.current_stream().synchronize()       # x must outlive the kernels
         self._n = n
+        self._raw = (x, dtype, sc, of)                      # saturation veto of the residual pass
 
     # ---------------------------------------------------------- find_triggers
     def find_triggers(self, thresh, pileup_window_msec=None, pileup_window_samples=None,
                       positive_pulses=True, dynamic=False, dynamic_threshold_function=None,
                       residual=False, saturation_amplitudes_LPF_50kHz=None,
                       edge_exclusion_msec=None, livetime=None, return_trigger_data=False):
-        """oftrigger.py:681-880 without the residual pass."""
+        """oftrigger.py:681-880."""
+        ret = None
         if residual:
-            raise NotImplementedError("the residual re-trigger pass is not on the GPU")
-        self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
-                                dynamic_threshold_function)
+            ret = self._find_triggers_residual(
+                thresh, pileup_window_msec, pileup_window_samples, positive_pulses, dynamic,
+                dynamic_threshold_function, saturation_amplitudes_LPF_50kHz, return_trigger_data)
+        else:
+            self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
+                                    dynamic_threshold_function)
         if edge_exclusion_msec is not None:
             tmin = edge_exclusion_msec * 1e-3
             tmax = self._n / self._fs - edge_exclusion_msec * 1e-3
@@ -235,14 +284,119 @@ class OptimumFilterTrigger:
                 if livetime is not None:
                     out[f"trigger_livetime_{chan}"] = [livetime] * len(keep)
                 self._trigger_data[chan] = out
+        return ret
+
+    # ------------------------------------------------------------ residual pass
+    def _pulse_table(self):
+        """G[a][b][z]: the delta-chi2 trace of a best-fit pulse with amplitudes A is
+        sum_ab A_a A_b G_ab[z] -- oftrigger.py:793-809 with the amplitudes taken out of the
+        convolutions.  The filter of amplitude theta is indexed as the reference indexes it in
+        this loop (``self._phi_td[theta, :]``, oftrigger.py:800; update_trace uses
+        ``[:, theta, :]``, :658): identical for one channel x one amplitude, and the
+        reference's own expression only runs when the two counts agree (or one is 1); other
+        shapes use the update_trace convention."""
+        from scipy.signal import oaconvolve
+        C_, M, T = self._n_channels, self._m_amplitudes, self._t_times
+        if C_ == 1 and M == 1:
+            iw_eff = np.array([[1.0 / (float(self._w_matrix[0, 0]) * self._fs)]])
+        else:
+            iw_eff = self._iw_matrix / self._fs
+        lit = (C_ == M) or C_ == 1 or M == 1
+        f = np.zeros((M, M, T))                            # f[a][i][z] = (iw U_a)[i][z]
+        for a in range(M):
+            U = np.zeros((M, T))
+            for theta in range(M):
+                kern = self._phi_td[theta] if lit else self._phi_td[:, theta, :]
+                kern = np.broadcast_to(kern, (C_, T)) if kern.shape[0] != C_ else kern
+                U[theta] = np.sum(oaconvolve(self._template[:, a, :], kern, mode="same", axes=-1),
+                                  axis=0)
+            f[a] = iw_eff @ U
+        return np.ascontiguousarray(np.einsum("aiz,ij,bjz->abz", f, self._w_matrix, f))
+
+    def _saturated(self, trigger_index, positive_pulses, sat):
+        """oftrigger.py:772-786: a first-pass trigger is vetoed when the 50 kHz low-passed raw
+        trace of any channel crosses its saturation amplitude within n_samples/4 of it."""
+        if all(not np.isfinite(v) for v in sat):
+            return False
+        x, dtype, sc, of = self._raw
+        q = int(self._t_times / 4)
+        lo, hi = trigger_index - q, trigger_index + q
+        if lo < 0 or hi <= lo:
+            return False
+        for ch in range(self._n_channels):
+            if not np.isfinite(sat[ch]):
+                continue
+            row = x[ch]
+            a0, a1 = max(0, lo - 1024), min(row.shape[-1], hi + 1024)
+            seg = row[a0:a1]
+            seg = seg.cpu().numpy() if not isinstance(seg, np.ndarray) else seg
+            seg = seg.astype(np.float64)
+            if dtype == 1:
+                seg = seg * sc[ch] + of[ch]
+            lp = _lowpass_50khz_window(seg, self._fs, lo - a0, min(hi, row.shape[-1]) - a0, pad=0)
+            if positive_pulses:
+                if np.sum(lp > sat[ch]) > 0:
+                    return True
+            elif np.sum(lp < -1 * sat[ch]) > 0:
+                return True
+        return False
+
+    def _find_triggers_residual(self, thresh, pileup_window_msec, pileup_window_samples,
+                                positive_pulses, dynamic, dynamic_threshold_function, sat,
+                                return_trigger_data):
+        import copy
+        if sat is None:
+            sat = [np.inf if positive_pulses else -np.inf] * self._n_channels
+        self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
+                                dynamic_threshold_function)
+        name = self._trigger_name
+        original_triggers = list(self._trigger_data[name]["trigger_index"])
+        original_trigger_data = copy.deepcopy(self._trigger_data)
+        if not getattr(self, "_pulse_set", False):
+            G = self._pulse_table()
+            _lib.check(self._lib.ofx_trigger_set_pulse_table(self._h, G.ctypes.data),
+                       "ofx_trigger_set_pulse_table")
+            self._pulse_set = True
+        keep = np.asarray([ti for ti in original_triggers
+                           if not self._saturated(int(ti), positive_pulses, sat)], dtype=np.int64)
+        _lib.check(self._lib.ofx_trigger_residual_subtract(
+            self._h, keep.ctypes.data if len(keep) else None, len(keep), None),
+            "ofx_trigger_residual_subtract")
+        self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
+                                dynamic_threshold_function)
+        new_triggers = list(self._trigger_data[name]["trigger_index"])
+        new_trigger_data = copy.deepcopy(self._trigger_data)
+        res = None
+        if return_trigger_data:
+            res = np.empty(self._n, dtype=np.float32)
+        _lib.check(self._lib.ofx_trigger_residual_restore(
+            self._h, res.ctypes.data if res is not None else None, _lib.MEM_HOST, None),
+            "ofx_trigger_residual_restore")
+        self._residual_delta_chi2_trace = res
+        # combine_trigger_data (oftrigger.py:262-320): second-pass triggers whose index is new
+        # are appended; the "<key>_<name>" entries are the same list objects as "<key>"
+        fresh = set(new_triggers) - set(original_triggers)
+        combined = copy.deepcopy(original_trigger_data[name])
+        newd = new_trigger_data[name]
+        for key in newd:
+            if ("_" + name) in key:
+                continue
+            if key not in combined:            # (first pass found nothing: no trigger_channel)
+                combined[key] = []
+                combined[key + "_" + name] = combined[key]
+            for i, trig in enumerate(new_triggers):
+                if trig in fresh:
+                    combined[key].append(newd[key][i])
+        self._trigger_data = {name: combined}
+        if return_trigger_data:
+            return original_trigger_data, self.get_filtered_delta_chi2(), new_trigger_data, res
+        return None
 
     def find_triggers_once(self, thresh, pileup_window_msec=None, pileup_window_samples=None,
                            dynamic=False, dynamic_threshold_function=None):
-        """oftrigger.py:884-1035 (static pile-up window)."""
+        """oftrigger.py:884-1035."""
         if self._n == 0:
             raise ValueError('ERROR: Filter trace not available.  Use "update_trace" first!')
-        if dynamic:
-            raise NotImplementedError("the dynamic pile-up window is not on the GPU")
         pileup_window = 0
         if pileup_window_msec is not None:
             pileup_window = int(pileup_window_msec * self._fs / 1000)
@@ -250,6 +404,34 @@ class OptimumFilterTrigger:
             pileup_window = int(pileup_window_samples)
         chi2_threshold = _chi2_threshold(thresh, self._m_amplitudes)
         self.chi2_threshold = chi2_threshold
+        if dynamic:
+            if dynamic_threshold_function is None:
+                raise ValueError('ERROR: "dynamic_threshold_function" required when dynamic=True')
+            idx_out, dchi_out, amp_out = self._find_dynamic(chi2_threshold,
+                                                            dynamic_threshold_function)
+        else:
+            idx_out, dchi_out, amp_out = self._find_static(chi2_threshold, pileup_window)
+        m = len(idx_out)
+        ind = idx_out + self._trigger_index_shift                       # oftrigger.py:1005
+        data = {
+            "trigger_delta_chi2": [float(v) for v in dchi_out],
+            "trigger_time": [float(v) for v in ind / self._fs],
+            "trigger_index": [int(v) for v in ind],
+            "trigger_pileup_window": [pileup_window] * m,
+            "trigger_threshold_sigma": [thresh] * m,
+            "trigger_type": [4] * m,
+        }
+        for iamp in range(self._m_amplitudes):                          # oftrigger.py:926-929
+            data[f"trigger_amplitude_{iamp}"] = [float(v) for v in amp_out[:, iamp]]
+        if self._m_amplitudes == 1:
+            data["trigger_amplitude"] = [float(v) for v in amp_out[:, 0]]
+        if m > 0:
+            data["trigger_channel"] = [str(self._trigger_name)] * m
+        self._trigger_data = {self._trigger_name: dict(data)}
+        for key, val in data.items():                                   # oftrigger.py:1031-1033
+            self._trigger_data[self._trigger_name][key + "_" + self._trigger_name] = val
+
+    def _find_static(self, chi2_threshold, pileup_window):
         cap = 1 << 16
         while True:
             idx = np.empty(cap, dtype=np.int64)
@@ -266,24 +448,37 @@ class OptimumFilterTrigger:
                 continue
             _lib.check(rc, "ofx_trigger_find")
         m = cnt.value
-        ind = idx[:m] + self._trigger_index_shift                       # oftrigger.py:1005
-        data = {
-            "trigger_delta_chi2": [float(v) for v in dchi[:m]],
-            "trigger_time": [float(v) for v in ind / self._fs],
-            "trigger_index": [int(v) for v in ind],
-            "trigger_pileup_window": [pileup_window] * m,
-            "trigger_threshold_sigma": [thresh] * m,
-            "trigger_type": [4] * m,
-        }
-        for iamp in range(self._m_amplitudes):                          # oftrigger.py:926-929
-            data[f"trigger_amplitude_{iamp}"] = [float(v) for v in amp[:m, iamp]]
-        if self._m_amplitudes == 1:
-            data["trigger_amplitude"] = [float(v) for v in amp[:m, 0]]
-        if m > 0:
-            data["trigger_channel"] = [str(self._trigger_name)] * m
-        self._trigger_data = {self._trigger_name: dict(data)}
-        for key, val in data.items():                                   # oftrigger.py:1031-1033
-            self._trigger_data[self._trigger_name][key + "_" + self._trigger_name] = val
+        return idx[:m], dchi[:m], amp[:m]
+
+    def _find_dynamic(self, chi2_threshold, threshold_function):
+        """oftrigger.py:982-986 + 993-1019: the device compacts the samples above threshold;
+        the ranges (a function of the running maximum through a Python callable) are cut here;
+        the first maximum of each range is the trigger."""
+        cap = 1 << 20
+        while True:
+            idx = np.empty(cap, dtype=np.int64)
+            dchi = np.empty(cap, dtype=np.float32)
+            cnt = C.c_longlong()
+            rc = self._lib.ofx_trigger_above(self._h, chi2_threshold, idx.ctypes.data,
+                                             dchi.ctypes.data, cap, C.byref(cnt), None)
+            if rc == 0:
+                break
+            if cnt.value > cap:
+                cap = int(cnt.value)
+                continue
+            _lib.check(rc, "ofx_trigger_above")
+        n = cnt.value
+        idx, dchi = idx[:n], dchi[:n]
+        picks = np.asarray([s + int(np.argmax(dchi[s:e]))
+                            for s, e in _dynamic_ranges(idx, dchi, threshold_function)],
+                           dtype=np.int64)
+        sel = np.ascontiguousarray(idx[picks]) if len(picks) else np.empty(0, dtype=np.int64)
+        amp = np.empty((len(sel), self._m_amplitudes), dtype=np.float32)
+        if len(sel):
+            _lib.check(self._lib.ofx_trigger_gather(self._h, sel.ctypes.data, len(sel),
+                                                    amp.ctypes.data, None, None),
+                       "ofx_trigger_gather")
+        return sel, dchi[picks] if len(picks) else np.empty(0, dtype=np.float32), amp
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -299,6 +299,41 @@ int ofx_trigger_find(ofx_trigger* trig, double chi2_threshold, long long pileup_
                      long long* index, float* delta_chi2, float* amplitude,
                      long long max_triggers, long long* n_triggers, void* stream);
 
+/*
+ * Pieces of find_triggers_once(dynamic=True) and find_triggers(residual=True)
+ * (detprocess/core/oftrigger.py:78-143, 752-845, 982-986).
+ *
+ * ofx_trigger_above: the samples with delta chi2 > chi2_threshold, compacted in ascending order
+ * (np.where(triggers_mask)[0] and delta_chi2[triggers_mask], oftrigger.py:976-978) into HOST
+ * arrays of capacity cap; *n receives their number (OFX_ERR_ARG if it exceeds cap).  The
+ * dynamic pile-up window is a user-supplied Python function of the running range maximum
+ * (_getchangeslessthandynamicthresh), so the caller segments this list on the host.
+ *
+ * ofx_trigger_gather: filtered amplitudes (m x n_amp floats, trigger-major) and delta chi2
+ * (may be NULL) at m stream indices (HOST arrays); indices outside the stream give 0.
+ *
+ * ofx_trigger_set_pulse_table: G[a][b][z], z < n_samples (fp64, host): the delta-chi2 trace
+ * of a best-fit pulse with amplitudes A is sum_ab A_a A_b G_ab[z] (oftrigger.py:793-809 with
+ * the amplitudes factored out of the convolutions).
+ *
+ * ofx_trigger_residual_subtract: for every trigger index ti (HOST array; as stored in
+ * trigger_index, i.e. with the pretrigger shift, as oftrigger.py:766-815 uses it): A =
+ * filtered[:, ti], pulse = sum_ab A_a A_b G_ab, j = first arg-max of pulse,
+ * delta_chi2[ti - j : ti - j + n_samples] -= pulse.  The first call after update_trace keeps
+ * a copy of the delta-chi2 trace; ofx_trigger_residual_restore copies the residual trace out
+ * (pointer may be NULL; mem = OFX_MEM_HOST / OFX_MEM_DEVICE) and puts the first-pass trace back
+ * (oftrigger.py:824-828).
+ */
+int ofx_trigger_above(ofx_trigger* trig, double chi2_threshold, long long* index,
+                      float* delta_chi2, long long cap, long long* n, void* stream);
+int ofx_trigger_gather(ofx_trigger* trig, const long long* index, long long m, float* amplitude,
+                       float* delta_chi2, void* stream);
+int ofx_trigger_set_pulse_table(ofx_trigger* trig, const double* G);
+int ofx_trigger_residual_subtract(ofx_trigger* trig, const long long* trigger_index, long long m,
+                                  void* stream);
+int ofx_trigger_residual_restore(ofx_trigger* trig, float* residual_delta_chi2, int mem,
+                                 void* stream);
+
 /* ------------------------------------------------------------------------
  * N-channel x M-template optimal filter.
  * Replaces, per batch of events, qp.OFnxm(of_base=, channels='a|b', template_tag=).calc()

@@ -568,3 +568,40 @@ def test_lds_three_slots_at_other_lengths(n):
             assert np.array_equal(out[:, o1:o1 + 8], so[:, o2:o2 + 8]), (kinds[s], n)
         solo.close()
     plan.close()
+
+
+def test_run_sharded_streaming_equals_resident():
+    """detprocess_amd.dist.run_sharded on the GPU: chunks generated on the producer stream
+    while the compute stream works (two buffers, event-ordered) give, bit for bit, the rows of
+    one pass over the resident shard -- also with a ragged last chunk and a single chunk."""
+    import torch
+    from detprocess_amd import OFPlan, SynthSource, build_filter
+    from detprocess_amd import dist as ofdist
+    n, pre = 32768, 16384
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    ft = build_filter(tmpl, psd, FS, pre)
+    gen = SynthSource(n, tmpl, psd, FS, 3 * ft.ampres, 300 * ft.ampres, 0.5, 2000, seed=5)
+    plan = OFPlan(n, pre, FS, max_batch=4096, engine="fused")
+    plan.set_filter(0, ft)
+    plan.add_search(0, "delay")
+    row = plan.row_floats
+    total = 700
+    shard = torch.empty((total, n), dtype=torch.float32, device="cuda:0")
+    gen.fill(0, total, shard)
+    torch.cuda.synchronize()
+    proc = lambda ev, out: plan.process(ev, out=out)
+    want = ofdist.run_sharded(total, total, shard, proc, row, (n,), device="cuda:0").clone()
+    for chunk in (128, 256, 699, 5000):
+        got = ofdist.run_sharded(total, chunk, gen.fill, proc, row, (n,), device="cuda:0")
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), chunk
+    # a rank's view of a two-rank run: its half, keyed by the global event index
+    lo, hi = ofdist.shard_range(total, 1, 2)
+    half = ofdist.run_sharded(total, 100, gen.fill, proc, row, (n,), rank=1, world=2,
+                              device="cuda:0", gather=False)
+    torch.cuda.synchronize()
+    assert torch.equal(half, want[lo:hi])
+    ref = orc.process_events(orc.OFFilter(tmpl, psd, FS, pre), shard[:16].cpu().numpy().astype(np.float64),
+                             "unconstrained")
+    check_search(want[:16].cpu().numpy().astype(np.float64), 0, ref, "", ft.ampres, FS, "sharded")

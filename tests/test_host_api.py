@@ -678,3 +678,43 @@ def test_command_line_driver(tmp_path):
     assert list(got["event_index"]) == list(range(B))
     for c in want.columns:
         assert np.array_equal(got[c].to_numpy(), want[c].to_numpy()), c
+
+
+def test_window_indices_table_of_the_product_helper():
+    """detprocess_amd.utils.get_window_indices (the host code the GPU plans are built from)
+    against the hand-derived table of features.py:1243-1344: int() truncates toward zero BEFORE
+    the pretrigger is added (-10 us -> 16372, not 16371), both ends clamp to [0, N-1], defaults
+    are 0 and N-1, max < min raises."""
+    from detprocess_amd import utils
+    g = utils.get_window_indices
+    N, pre = 32768, 16384
+    assert g(N, pre, FS) == (0, N - 1)
+    assert g(N, pre, FS, window_min_from_trig_usec=-10, window_max_from_trig_usec=10) == (16372, 16396)
+    assert g(N, pre, FS, window_min_from_trig_usec=-400, window_max_from_trig_usec=400) == (15884, 16884)
+    assert g(N, pre, FS, window_min_from_start_usec=100) == (125, N - 1)
+    assert g(N, pre, FS, window_max_to_end_usec=100) == (0, N - 125 - 1)
+    assert g(N, pre, FS, window_min_to_end_usec=1000, window_max_to_end_usec=100) == (N - 1251, N - 126)
+    assert g(N, pre, FS, window_min_to_end_usec=-1000, window_max_to_end_usec=-100) == (N - 1251, N - 126)
+    assert g(N, pre, FS, window_min_from_trig_usec=-1e9) == (0, N - 1)
+    assert g(N, pre, FS, window_max_from_trig_usec=1e9) == (0, N - 1)
+    assert g(N, pre, FS, window_min_from_start_usec=0, window_max_from_trig_usec=-2000) == (0, pre - 2500)
+    assert g(N, pre, FS, window_min_from_trig_usec=2000, window_max_to_end_usec=0) == (pre + 2500, N - 1)
+    assert g(25000, 12500, FS, window_min_from_trig_usec=-400, window_max_from_trig_usec=400) == (12000, 13000)
+    # non-integer products truncate toward zero on both sides of the trigger
+    assert g(N, pre, 1.0e6, window_min_from_trig_usec=-10.7, window_max_from_trig_usec=10.7) == (pre - 10, pre + 10)
+    # precedence: from_start wins over to_end wins over from_trig (features.py:1305-1335)
+    assert g(N, pre, FS, window_min_from_start_usec=8, window_min_from_trig_usec=-10) == (10, N - 1)
+    assert g(N, pre, FS, unknown_key=3) == (0, N - 1)
+    with pytest.raises(ValueError, match="max index smaller than min"):
+        g(N, pre, FS, window_min_from_trig_usec=10, window_max_from_trig_usec=-10)
+    assert utils.extract_window_indices is utils.get_window_indices
+
+
+def test_duplicate_yaml_keys_are_refused():
+    from detprocess_amd import YamlConfig
+    bad = "A:\n    baseline:\n        run: True\n    baseline:\n        run: False\n"
+    with pytest.raises(ValueError, match='Duplicate key "baseline"'):
+        YamlConfig(bad, ["A"], sample_rate=FS)
+    bad2 = "A:\n    baseline:\n        run: True\n        run: False\n"
+    with pytest.raises(ValueError, match='Duplicate key "run"'):
+        YamlConfig(bad2, ["A"], sample_rate=FS)
