@@ -144,13 +144,20 @@ def _usable_cores():
     """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota
     (a GPU box shows every host core in the mask but grants a share of them)."""
     n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
-    except (OSError, ValueError):
-        pass
-    return n
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None),
+                                    ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us",
+                                     "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_file is None:
+                quota, period = open(quota_file).read().split()[:2]
+            else:
+                quota, period = open(quota_file).read().strip(), open(period_file).read().strip()
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            continue
+    return min(n, 64)          # one process per core; more than this only measures fork time
 
 
 def cpu_baseline(config, seconds=8.0):

@@ -122,8 +122,6 @@ class FeatureExtractors:
                 raise ValueError(f'ERROR: Wrong length for "amplitude_names" argument. Expecting '
                                  f'{ntmps} name for  channel {channel}, algorithm '
                                  f'"{feature_base_name}"')
-        if interpolate_t0:
-            raise ValueError('ERROR: "interpolate_t0" is not supported by the GPU NxM filter')
         ret = {f"chi2_{feature_base_name}_constrained": SENTINEL,
                f"t0_{feature_base_name}_constrained": SENTINEL}
         for name in amplitude_names:
@@ -136,7 +134,8 @@ class FeatureExtractors:
         lo, hi = search_range(template.shape[-1], of_base.pretrigger_samples(channel, template_tag),
                               of_base.sample_rate(), window_min_from_trig_usec,
                               window_max_from_trig_usec, window_min_index, window_max_index)
-        r = of_base.fit_nxm(channel, template_tag, lo, hi, bool(lgc_outside_window))
+        r = of_base.fit_nxm(channel, template_tag, lo, hi, bool(lgc_outside_window),
+                            interpolate=bool(interpolate_t0))
         sq = of_base.squeeze(channel)
         ret[f"chi2_{feature_base_name}_constrained"] = _maybe_scalar(r["chi2"], sq)
         ret[f"t0_{feature_base_name}_constrained"] = _maybe_scalar(r["t0"], sq)

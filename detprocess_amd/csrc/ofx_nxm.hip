@@ -25,6 +25,7 @@ struct NxmSearch {
     int kind;          // OFX_SEARCH_NODELAY / OFX_SEARCH_DELAY
     int lo, hi;        // half-open rolled range
     int outside;
+    int interp;        // OFX_SEARCH_DELAY_INTERP: interpolate_t0 (algorithms.py:152, 259)
 };
 
 struct NxmParams {
@@ -272,8 +273,46 @@ k_nxm_search(NxmParams p, const float* __restrict__ qt, const float* __restrict_
                 for (int l = 0; l < M; ++l) t += p.pinv[m * M + l] * qv[l];
                 rec[m] = t;
             }
-            rec[M] = (float)(best - p.pre) * p.inv_fs;
-            rec[M + 1] = chi0 - nxm_quad<M>(qv, p.pinv);
+            const float r0 = nxm_quad<M>(qv, p.pinv);
+            float frac = 0.0f, chi2 = chi0 - r0;
+            if (sr.interp && best > 0 && best < p.N - 1) {
+                // interpolate_t0: vertex of the parabola through chi2 = chi0 - q^T P^-1 q at
+                // the rolled bins best-1, best, best+1; every amplitude from its own parabola
+                // at the same offset (the of1x1 rule, ofx_interpolate / oracle interpolate_of)
+                float qm[M], qp[M], am[M], ap[M];
+                const int nm = (n == 0) ? p.N - 1 : n - 1, np_ = (n == p.N - 1) ? 0 : n + 1;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    qm[m] = qe[(size_t)m * p.N + nm];
+                    qp[m] = qe[(size_t)m * p.N + np_];
+                }
+                const float rm = nxm_quad<M>(qm, p.pinv), rp = nxm_quad<M>(qp, p.pinv);
+                const float dpm = rp - rm;                       // y(-1) - y(+1)
+                const float den = (r0 - rm) + (r0 - rp);         // y(-1) - 2 y(0) + y(+1)
+                if (den > 0.0f) {
+                    const float x = 0.5f * dpm / den;
+                    if (fabsf(x) <= 1.0f) {
+                        frac = x;
+                        chi2 = chi2 - 0.125f * dpm * dpm / den;
+#pragma unroll
+                        for (int m = 0; m < M; ++m) {
+                            float tm = 0.0f, tp = 0.0f;
+#pragma unroll
+                            for (int l = 0; l < M; ++l) {
+                                tm += p.pinv[m * M + l] * qm[l];
+                                tp += p.pinv[m * M + l] * qp[l];
+                            }
+                            am[m] = tm;
+                            ap[m] = tp;
+                            const float a0 = rec[m];
+                            rec[m] = a0 + 0.5f * (ap[m] - am[m]) * x +
+                                     0.5f * ((am[m] - a0) + (ap[m] - a0)) * x * x;
+                        }
+                    }
+                }
+            }
+            rec[M] = ((float)(best - p.pre) + frac) * p.inv_fs;
+            rec[M + 1] = chi2;
             rec[M + 2] = (float)best;
         }
     }
@@ -510,8 +549,10 @@ extern "C" int ofx_nxm_set_filter(ofx_nxm* p, const double* phi, const double* i
 }
 
 extern "C" int ofx_nxm_add_search(ofx_nxm* p, int kind, int lo, int hi, int outside) {
-    if (!p || (kind != OFX_SEARCH_NODELAY && kind != OFX_SEARCH_DELAY)) {
-        ofx_set_error("ofx_nxm_add_search: kind must be OFX_SEARCH_NODELAY or OFX_SEARCH_DELAY");
+    if (!p || (kind != OFX_SEARCH_NODELAY && kind != OFX_SEARCH_DELAY &&
+               kind != OFX_SEARCH_DELAY_INTERP)) {
+        ofx_set_error("ofx_nxm_add_search: kind must be OFX_SEARCH_NODELAY, OFX_SEARCH_DELAY or "
+                      "OFX_SEARCH_DELAY_INTERP");
         return -OFX_ERR_ARG;
     }
     if ((int)p->searches.size() >= NXM_MAX_SEARCHES) {
@@ -519,7 +560,8 @@ extern "C" int ofx_nxm_add_search(ofx_nxm* p, int kind, int lo, int hi, int outs
         return -OFX_ERR_ARG;
     }
     NxmSearch s;
-    s.kind = kind;
+    s.interp = (kind == OFX_SEARCH_DELAY_INTERP) ? 1 : 0;
+    s.kind = s.interp ? OFX_SEARCH_DELAY : kind;
     s.lo = lo < 0 ? 0 : lo;
     s.hi = hi > p->N ? p->N : hi;
     if (s.hi < s.lo) s.hi = s.lo;

@@ -302,13 +302,13 @@ class OFBase:
         self._fit_cache[ck] = res
         return res
 
-    def fit_nxm(self, channel, template_tag, lo=0, hi=None, outside=False):
+    def fit_nxm(self, channel, template_tag, lo=0, hi=None, outside=False, interpolate=False):
         """qp.OFnxm(...).calc() + get_fit_withdelay + get_fit_nodelay (algorithms.py:241-262) on
         the stored batch of an 'a|b' channel.  Returns dict: amps [B, M], t0, chi2,
         amps_nodelay [B, M], chi2_nodelay."""
         if not self.is_signal_stored(channel):
             raise ValueError(f"ERROR: no signal stored for channel {channel}")
-        ck = (channel, template_tag, "nxm", lo, hi, bool(outside))
+        ck = (channel, template_tag, "nxm", lo, hi, bool(outside), bool(interpolate))
         if ck in self._fit_cache:
             return self._fit_cache[ck]
         tab = self.nxm_tables(channel, template_tag)
@@ -328,7 +328,7 @@ class OFBase:
                 ev = torch.stack(sigs, dim=1)
         plan.reset_searches()
         s_nd = plan.add_search("nodelay")
-        s_d = plan.add_search("delay", lo, hi, outside)
+        s_d = plan.add_search("delay", lo, hi, outside, interpolate)
         out = plan.process(ev)
         if not isinstance(out, np.ndarray):
             out = out.cpu().numpy()

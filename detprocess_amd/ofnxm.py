@@ -108,9 +108,12 @@ class NxMPlan:
                                                 pinv.ctypes.data), "ofx_nxm_set_filter")
         self.searches = []
 
-    def add_search(self, kind, lo=0, hi=None, outside=False):
-        """kind 'nodelay' or 'delay' over rolled bins [lo, hi); returns the search id."""
+    def add_search(self, kind, lo=0, hi=None, outside=False, interpolate=False):
+        """kind 'nodelay' or 'delay' over rolled bins [lo, hi); interpolate: the delay fit's
+        interpolate_t0 (algorithms.py:152, 259); returns the search id."""
         k = {"nodelay": _lib.SEARCH_NODELAY, "delay": _lib.SEARCH_DELAY}[kind]
+        if interpolate and kind == "delay":
+            k = _lib.SEARCH_DELAY_INTERP
         hi = self.n_samples if hi is None else hi
         sid = self._lib.ofx_nxm_add_search(self._h, k, int(lo), int(hi), int(bool(outside)))
         if sid < 0:

@@ -360,8 +360,6 @@ class FeatureProcessing:
             if "template_tag" not in params:
                 raise ValueError(f'ERROR: a "template_tag" in yaml file is required for channel '
                                  f'{channel}, algorithm "{algorithm}" !')
-            if params.get("interpolate_t0", False):
-                raise ValueError('ERROR: "interpolate_t0" is not supported by the GPU NxM filter')
             peaks = params.get("ignored_frequency_peaks")
             if peaks is not None and not isinstance(peaks, list):
                 peaks = [peaks]
@@ -415,7 +413,8 @@ class FeatureProcessing:
                                       params.get("window_max_from_trig_usec"), wmin, wmax,
                                       self._policy)
                 s_d = plan.add_search("delay", lo, hi,
-                                      bool(params.get("lgc_outside_window", False)))
+                                      bool(params.get("lgc_outside_window", False)),
+                                      bool(params.get("interpolate_t0", False)))
                 od, on = s_d * (m + 3), s_nd * (m + 3)
                 cp.columns.append((f"chi2_{algorithm}_constrained_{feature_channel}", od + m + 1))
                 cp.columns.append((f"t0_{algorithm}_constrained_{feature_channel}", od + m))

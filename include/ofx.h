@@ -358,8 +358,9 @@ int ofx_nxm_destroy(ofx_nxm* nxm);
  */
 int ofx_nxm_set_filter(ofx_nxm* nxm, const double* phi, const double* icov, const double* pinv);
 
-/* kind OFX_SEARCH_NODELAY (n = 0) or OFX_SEARCH_DELAY over rolled bins [lo, hi) (outside != 0:
- * the complement).  Returns the search id (>= 0) or -OFX_ERR_*.  Output record of search s:
+/* kind OFX_SEARCH_NODELAY (n = 0), OFX_SEARCH_DELAY over rolled bins [lo, hi) (outside != 0:
+ * the complement) or OFX_SEARCH_DELAY_INTERP (the same with interpolate_t0: parabolic refinement
+ * of t0, chi2 and every amplitude around the discrete minimum, algorithms.py:152, 259).  Returns the search id (>= 0) or -OFX_ERR_*.  Output record of search s:
  * floats [s (n_tmpl + 3) ...]: amplitudes (n_tmpl), t0 (s), chi2, rolled index. */
 int ofx_nxm_add_search(ofx_nxm* nxm, int kind, int lo, int hi, int outside);
 int ofx_nxm_reset_searches(ofx_nxm* nxm);

@@ -82,8 +82,12 @@ def signal_products(filt, x):
 
 def fit(filt, x, window_min_from_trig_usec=None, window_max_from_trig_usec=None,
         window_min_index=None, window_max_index=None, lgc_outside_window=False,
-        window_policy="qetpy"):
-    """One event: dict with the no-delay and the windowed delay fit."""
+        window_policy="qetpy", interpolate_t0=False):
+    """One event: dict with the no-delay and the windowed delay fit.  interpolate_t0
+    (algorithms.py:152, 259 -> qp.OFnxm.get_fit_withdelay, unseen): restated by analogy with
+    the single-template helper (oracle/of1x1.py interpolate_of): vertex of the parabola through
+    chi2 at the three bins around the discrete minimum, every amplitude from its own parabola at
+    that offset; same guards."""
     q, chi0 = signal_products(filt, x)
     red = np.einsum("mn,ml,ln->n", q, filt.Pinv, q)
     chi2 = chi0 - red
@@ -94,7 +98,17 @@ def fit(filt, x, window_min_from_trig_usec=None, window_max_from_trig_usec=None,
     if i is None:
         out.update(amps=np.full(filt.M, -999999.0), t0=-999999.0, chi2=-999999.0, index=-1)
     else:
-        out.update(amps=filt.Pinv @ q[:, i], t0=(i - filt.pre) / filt.fs, chi2=chi2[i], index=i)
+        amps, t0, c2 = filt.Pinv @ q[:, i], (i - filt.pre) / filt.fs, chi2[i]
+        if interpolate_t0 and 0 < i < filt.N - 1:
+            y0, y1, y2 = chi2[i - 1], chi2[i], chi2[i + 1]
+            den = y0 - 2.0 * y1 + y2
+            if den > 0.0 and abs(0.5 * (y0 - y2) / den) <= 1.0:
+                xv = 0.5 * (y0 - y2) / den
+                am, ap = filt.Pinv @ q[:, i - 1], filt.Pinv @ q[:, i + 1]
+                amps = amps + 0.5 * (ap - am) * xv + 0.5 * (am - 2.0 * amps + ap) * xv * xv
+                t0 = t0 + xv / filt.fs
+                c2 = y1 - 0.125 * (y0 - y2) ** 2 / den
+        out.update(amps=amps, t0=t0, chi2=c2, index=i)
     out["chi2_0"] = chi0
     return out
 

@@ -4,9 +4,15 @@ optimal-filter trigger of detprocess (``OFTrigger``: single channel x single amp
 
     OptimumFilterTrigger.__init__          detprocess/core/oftrigger.py:384-499
     OptimumFilterTrigger.update_trace      detprocess/core/oftrigger.py:588-679
-    OptimumFilterTrigger.find_triggers_once  :884-1035   (static pile-up window)
+    OptimumFilterTrigger.find_triggers_once  :884-1035   (static and dynamic pile-up window)
     _getchangeslessthanthresh              :29-77
+    _getchangeslessthandynamicthresh       :78-143
+    find_triggers(residual=True)           :752-845  (saturation veto, pulse subtraction in
+                                            delta-chi2 space, re-trigger, combine_trigger_data
+                                            :262-320)
     edge exclusion of find_triggers        :851-880
+qp.utils.lowpassfilter (oftrigger.py:629-633; QETpy, unseen) is restated as a first-order
+Butterworth run through scipy.signal.filtfilt with even padding.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this module.
 
@@ -27,6 +33,69 @@ from scipy import special, stats
 from scipy.signal import oaconvolve
 
 from . import of1x1
+
+
+def dynamic_ranges(x, amplitudes, threshold_function):
+    """_getchangeslessthandynamicthresh, oftrigger.py:111-135, literally: the maximum of the
+    current range is recomputed from its start at every step."""
+    starts, ends, cur = [], [], 0
+    for i in range(1, len(x)):
+        if (x[i] - x[i - 1]) > threshold_function(np.max(amplitudes[cur:i + 1])):
+            starts.append(cur)
+            ends.append(i)
+            cur = i
+    starts.append(cur)
+    ends.append(len(x))
+    return list(zip(starts, ends))
+
+
+def lowpass_50khz(trace, fs):
+    """qp.utils.lowpassfilter(trace, cut_off_freq=50e3, fs=fs): butter(1) + filtfilt(even)."""
+    from scipy.signal import butter, filtfilt
+    b, a = butter(1, 50e3 / (0.5 * fs))
+    return filtfilt(b, a, np.asarray(trace, dtype=np.float64), padtype="even")
+
+
+def _ranges(trig, dchi, window, dynamic_function):
+    if dynamic_function is not None:
+        return dynamic_ranges(trig, dchi[trig], dynamic_function) if len(trig) else []
+    if not len(trig):
+        return []
+    cuts = np.where((trig[1:] - trig[:-1]) > window)[0] + 1
+    return list(zip(np.concatenate(([0], cuts)), np.concatenate((cuts, [len(trig)]))))
+
+
+def residual_pass(obj, find_once, trigger_index, positive_pulses, saturation, raw, pulse_of):
+    """find_triggers(residual=True), oftrigger.py:752-845, shared by the two oracle classes:
+    returns (first-pass result, second-pass result, residual delta-chi2 trace, combined index
+    list in the order combine_trigger_data produces)."""
+    first = find_once()
+    original = np.copy(obj.delta_chi2)
+    T = obj.N
+    lp = None
+    for ti in first["trigger_index"]:
+        saturated = False
+        for ch in range(raw.shape[0]):
+            if not np.isfinite(saturation[ch]):
+                continue
+            if lp is None:
+                lp = np.stack([lowpass_50khz(r, obj.fs) for r in raw])
+            seg = lp[ch][ti - int(T / 4): ti + int(T / 4)]
+            if positive_pulses:
+                saturated |= bool(np.sum(seg > saturation[ch]) > 0)
+            else:
+                saturated |= bool(np.sum(seg < -1 * saturation[ch]) > 0)
+        if saturated:
+            continue
+        pulse = pulse_of(ti)                        # delta chi2 of the best-fit pulse, length T
+        j = int(np.argmax(pulse))
+        obj.delta_chi2[ti - j: ti - j + T] -= pulse
+    second = find_once()
+    residual = np.copy(obj.delta_chi2)
+    obj.delta_chi2 = original
+    fresh = set(second["trigger_index"].tolist()) - set(first["trigger_index"].tolist())
+    combined = list(first["trigger_index"]) + [t for t in second["trigger_index"] if t in fresh]
+    return first, second, residual, np.asarray(combined, dtype=np.int64)
 
 
 class OFTrigger:
@@ -74,9 +143,28 @@ class OFTrigger:
             return float(special.gammainccinv(m_amplitudes / 2, sf) * 2)
         return float(thresh) ** 2
 
+    def find_triggers_residual(self, thresh, raw, pileup_window_samples=None,
+                               dynamic_function=None, positive_pulses=True, saturation=None):
+        """oftrigger.py:752-845 for one channel x one amplitude."""
+        from scipy.signal import oaconvolve as oac
+        raw = np.asarray(raw, dtype=np.float64).reshape(1, -1)
+        if saturation is None:
+            saturation = [np.inf if positive_pulses else -np.inf]
+
+        def pulse_of(ti):
+            amp = self.filtered[ti]                               # oftrigger.py:792
+            trig_trace = self.template * amp
+            v = oac(trig_trace, self.phi_td, mode="same")
+            filt = v / self.vscale
+            return filt * self.w * filt
+
+        once = lambda: self.find_triggers(thresh, pileup_window_samples=pileup_window_samples,
+                                          dynamic_function=dynamic_function)
+        return residual_pass(self, once, None, positive_pulses, saturation, raw, pulse_of)
+
     def find_triggers(self, thresh, pileup_window_msec=None, pileup_window_samples=None,
-                      edge_exclusion_msec=None):
-        """find_triggers_once (static window) + the edge exclusion of find_triggers.
+                      edge_exclusion_msec=None, dynamic_function=None):
+        """find_triggers_once (static or dynamic window) + the edge exclusion of find_triggers.
         Returns dict of arrays: trigger_index, trigger_time, trigger_delta_chi2,
         trigger_amplitude."""
         window = 0
@@ -88,18 +176,15 @@ class OFTrigger:
         mask = self.delta_chi2 > thr
         trig = np.where(mask)[0]
         idx, dchi, amp = [], [], []
-        if len(trig):
-            # _getchangeslessthanthresh: split where consecutive indices differ by > window
-            cuts = np.where((trig[1:] - trig[:-1]) > window)[0] + 1
-            starts = np.concatenate(([0], cuts))
-            ends = np.concatenate((cuts, [len(trig)]))
-            for s, e in zip(starts, ends):
-                if e > s:
-                    inds = trig[s:e]
-                    i = inds[np.argmax(self.delta_chi2[inds])]
-                    idx.append(i + self.index_shift)
-                    dchi.append(self.delta_chi2[i])
-                    amp.append(self.filtered[i])
+        # _getchangeslessthanthresh: split where consecutive indices differ by > window;
+        # _getchangeslessthandynamicthresh when a window function is given
+        for s, e in _ranges(trig, self.delta_chi2, window, dynamic_function):
+            if e > s:
+                inds = trig[s:e]
+                i = inds[np.argmax(self.delta_chi2[inds])]
+                idx.append(i + self.index_shift)
+                dchi.append(self.delta_chi2[i])
+                amp.append(self.filtered[i])
         idx = np.asarray(idx, dtype=np.int64)
         out = {"trigger_index": idx, "trigger_time": idx / self.fs,
                "trigger_delta_chi2": np.asarray(dchi, dtype=np.float64),
@@ -127,6 +212,7 @@ class OFTriggerNxM:
         self.filt = ofnxm.NxMFilter(templates, csd, fs, pretrigger_samples, "AC",
                                     ignored_frequency_peaks, ignore_harmonics)
         self.C, self.M, self.N = self.filt.C, self.filt.M, self.filt.N
+        self._templates = np.asarray(templates, dtype=np.float64)
         self.pre = int(pretrigger_samples)
         phi_fd = np.transpose(self.filt.phi, (2, 1, 0)).copy()        # [b, m, k]
         phi_fd[:, :, 0] = 0.0                                         # oftrigger.py:488
@@ -152,7 +238,34 @@ class OFTriggerNxM:
             self.delta_chi2[-(cut) + (cut + 1) % 2:] = 0.0
         return self.filtered, self.delta_chi2
 
-    def find_triggers(self, thresh, pileup_window_msec=None, pileup_window_samples=None):
+    def find_triggers_residual(self, thresh, raw, pileup_window_samples=None,
+                               dynamic_function=None, positive_pulses=True, saturation=None):
+        """oftrigger.py:752-845, N x M.  The filter of amplitude theta is indexed as the
+        reference indexes it in this loop (``self._phi_td[theta, :]``, :800), which runs when
+        the channel and amplitude counts agree."""
+        raw = np.asarray(raw, dtype=np.float64)
+        if saturation is None:
+            saturation = [np.inf if positive_pulses else -np.inf] * self.C
+        tmpl = self._templates
+
+        def pulse_of(ti):
+            amps = self.filtered[:, ti]
+            trig_trace = np.zeros((self.C, self.N))
+            for m in range(self.M):
+                trig_trace += tmpl[:, m, :] * amps[m]
+            v_td = np.zeros((self.M, self.N))
+            for theta in range(self.M):
+                v_td[theta] = np.sum(oaconvolve(trig_trace, self.phi_td[theta, :], mode="same",
+                                                axes=-1), axis=0)
+            filt = np.einsum("ij,jz->iz", self.iw_matrix / self.fs, v_td)
+            return np.einsum("iz,ij,jz->z", filt, self.w_matrix, filt)
+
+        once = lambda: self.find_triggers(thresh, pileup_window_samples=pileup_window_samples,
+                                          dynamic_function=dynamic_function)
+        return residual_pass(self, once, None, positive_pulses, saturation, raw, pulse_of)
+
+    def find_triggers(self, thresh, pileup_window_msec=None, pileup_window_samples=None,
+                      dynamic_function=None):
         window = 0
         if pileup_window_msec is not None:
             window = int(pileup_window_msec * self.fs / 1000)
@@ -161,14 +274,12 @@ class OFTriggerNxM:
         thr = OFTrigger.chi2_threshold(thresh, self.M)
         trig = np.where(self.delta_chi2 > thr)[0]
         idx, dchi, amp = [], [], []
-        if len(trig):
-            cuts = np.where((trig[1:] - trig[:-1]) > window)[0] + 1
-            for s, e in zip(np.concatenate(([0], cuts)), np.concatenate((cuts, [len(trig)]))):
-                inds = trig[s:e]
-                i = inds[np.argmax(self.delta_chi2[inds])]
-                idx.append(i + self.index_shift)
-                dchi.append(self.delta_chi2[i])
-                amp.append(self.filtered[:, i])
+        for s, e in _ranges(trig, self.delta_chi2, window, dynamic_function):
+            inds = trig[s:e]
+            i = inds[np.argmax(self.delta_chi2[inds])]
+            idx.append(i + self.index_shift)
+            dchi.append(self.delta_chi2[i])
+            amp.append(self.filtered[:, i])
         idx = np.asarray(idx, dtype=np.int64)
         return {"trigger_index": idx, "trigger_time": idx / self.fs,
                 "trigger_delta_chi2": np.asarray(dchi, dtype=np.float64),

@@ -421,3 +421,45 @@ def test_nxm_properties_at_full_size():
     assert torch.equal(ir.long(), i_un.long() + d)
     assert torch.allclose(ar, a_un, rtol=2e-5, atol=1e-4 * float(tab.ampres.max()))
     assert torch.allclose(cr, c_un, rtol=2e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,pre,C,M", [(4096, 2048, 2, 2), (32768, 16384, 3, 2)])
+def test_nxm_interpolate_t0(n, pre, C, M):
+    """interpolate_t0 (algorithms.py:152, 259): the refined delay fit against the oracle's
+    restatement, on pulses clear of the noise (the sub-sample offset is a ratio of differences
+    whose fp32 error scales as 1 / SNR, as for of1x1); the time bin itself stays exact, and
+    the unrefined search of the same plan is untouched."""
+    from detprocess_amd.ofnxm import NxMPlan, build_nxm_filter, nxm_search_range
+    t = make_templates(n, pre, C, M)
+    csd = make_csd(n, C)
+    filt = onm.NxMFilter(t, csd, FS, pre)
+    ev, _, _ = make_events(32, t, csd, filt.ampres, seed=3, max_delay=min(n // 8, 2000))
+    plan = NxMPlan(build_nxm_filter(t, csd, FS, pre), max_batch=16)
+    lo, hi = nxm_search_range(n, pre, FS, -400, 400)
+    s_plain = plan.add_search("delay", lo, hi)
+    s_int = plan.add_search("delay", lo, hi, interpolate=True)
+    s_full = plan.add_search("delay", interpolate=True)
+    x32 = ev.astype(np.float32)
+    out = plan.process(x32).astype(np.float64)
+    x = x32.astype(np.float64)
+    _check(plan, out, s_plain, onm.process_events(filt, x, window_min_from_trig_usec=-400,
+                                                  window_max_from_trig_usec=400), filt)
+    for sid, kw in ((s_int, dict(window_min_from_trig_usec=-400, window_max_from_trig_usec=400)),
+                    (s_full, {})):
+        ref = onm.process_events(filt, x, interpolate_t0=True, **kw)
+        amps, t0, chi2, idx = plan.record(out, sid)
+        assert np.array_equal(idx.astype(np.int64), ref["index"])
+        snr = np.sqrt(np.maximum(ref["chi2_0"] - ref["chi2"], 0.0))
+        hi_snr = snr > 50
+        assert hi_snr.sum() >= 5
+        assert np.all(np.abs(t0 - ref["t0"])[hi_snr] <= 2e-3 / FS)
+        assert np.all(np.abs(t0 * FS - (idx - pre)) <= 1.0 + 1e-6)          # within one bin
+        ra = ref["amps"]
+        assert np.all((np.abs(amps - ra) <= 3e-5 * np.abs(ra) + 2e-4 * filt.ampres)[hi_snr])
+        assert np.all((np.abs(chi2 - ref["chi2"]) <= CHI_RTOL * np.abs(ref["chi2"])
+                       + 4e-6 * ref["chi2_0"])[hi_snr])
+    # refined and unrefined differ (the refinement does something) but by less than a bin
+    _, t0p, _, _ = plan.record(out, s_plain)
+    _, t0i, _, _ = plan.record(out, s_int)
+    assert np.any(t0p != t0i) and np.all(np.abs(t0p - t0i) <= 1.0 / FS + 1e-12)

@@ -334,3 +334,163 @@ chanA:
         assert abs(round(row["t0_of1x1_constrained_chanA"] * FS) + (found[hit[0]] - (p + pre))) <= 1
         checked += 1
     assert checked >= 5
+
+
+# ------------------------------------------------- dynamic window, residual pass, saturation
+def test_dynamic_ranges_of_the_product_equal_the_literal_restatement():
+    """detprocess_amd.oftrigger._dynamic_ranges (running maximum, cached window) against the
+    oracle's literal restatement of _getchangeslessthandynamicthresh (oftrigger.py:78-143)."""
+    from detprocess_amd.oftrigger import _dynamic_ranges
+    rng = np.random.default_rng(4)
+    fns = [lambda a: 3.0, lambda a: 0.5, lambda a: 2.0 + 0.02 * a, lambda a: 40.0 / (1.0 + a)]
+    for trial in range(40):
+        m = int(rng.integers(1, 300))
+        x = np.sort(rng.choice(5000, size=m, replace=False))
+        a = rng.exponential(100.0, size=m)
+        for fn in fns:
+            assert _dynamic_ranges(x, a, fn) == ot.dynamic_ranges(x, a, fn)
+    # nothing above threshold: the reference's helper yields the empty range (0, 0), which
+    # find_triggers_once skips (oftrigger.py:997); the product returns no range at all
+    assert _dynamic_ranges(np.array([], dtype=np.int64), np.array([]), fns[0]) == []
+    assert ot.dynamic_ranges(np.array([], dtype=np.int64), np.array([]), fns[0]) == [(0, 0)]
+    # the pile-up window grows with the range maximum: a large excursion swallows what follows
+    x = np.array([10, 11, 12, 40, 41, 100])
+    a = np.array([30.0, 900.0, 30.0, 35.0, 30.0, 31.0])
+    assert _dynamic_ranges(x, a, lambda v: 5.0 if v < 100 else 50.0) == [(0, 5), (5, 6)]
+    assert _dynamic_ranges(x, a, lambda v: 5.0) == [(0, 3), (3, 5), (5, 6)]
+
+
+def test_oracle_residual_pass_finds_the_piled_up_pulse():
+    """Known answer for oftrigger.py:752-845: a small pulse on the tail of a large one is
+    hidden by a long static pile-up window; after the large pulse's delta-chi2 shape is
+    subtracted the re-trigger finds it; a saturation veto on the large pulse keeps it hidden."""
+    # (pretrigger = n/2: the reference reads the amplitude and places the subtraction at the
+    # stored trigger index, which carries the shift pretrigger - n//2, oftrigger.py:766-815)
+    n, pre, L = 4096, 2048, 120000
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    t = ot.OFTrigger(FS, tmpl, psd, pre)
+    x = np.zeros(L)
+    big, small = 30000, 30700
+    x[big:big + n] += 2e-7 * tmpl
+    x[small:small + n] += 0.5e-7 * tmpl
+    x[80000:80000 + n] += 1e-7 * tmpl
+    t.update_trace(x)
+    first, second, residual, combined = t.find_triggers_residual(5.0, x, pileup_window_samples=3000)
+    assert list(first["trigger_index"]) == [big + pre + 1, 80000 + pre + 1]
+    assert abs(int(second["trigger_index"][0]) - (small + pre + 1)) <= 2
+    assert len(combined) == 3 and set(first["trigger_index"]) < set(combined)
+    assert np.max(residual) < 0.1 * np.max(t.delta_chi2)
+    # the first-pass trace is restored
+    assert np.max(t.delta_chi2) == pytest.approx((2e-7) ** 2 * t.w, rel=0.05)
+    sat = [1.5e-7]
+    f2, s2, res2, comb2 = t.find_triggers_residual(5.0, x, pileup_window_samples=3000, saturation=sat)
+    assert list(comb2[:2]) == list(first["trigger_index"])
+    assert len(comb2) == 2                      # vetoed: nothing subtracted, nothing new found
+    assert np.max(res2[big + pre - 50: big + pre + 50]) > 0.9 * (2e-7) ** 2 * t.w
+
+
+def _pileup_stream(n, pre, L, seed):
+    tmpl, psd, t, x, onsets, amps = _stream(n, pre, L, seed=seed, n_pulses=10)
+    rng = np.random.default_rng(seed + 1)
+    extra = []
+    for p in onsets[::2]:                        # a small pulse on the tail of every other one
+        q = int(p + rng.integers(n // 8, n // 3))
+        if q + n < L:
+            x[q:q + n] += t.resolution * rng.uniform(12, 25) * tmpl
+            extra.append(q)
+    return tmpl, psd, t, x, onsets, np.asarray(extra)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,pre,L", [(4096, 1500, 400000), (4096, 2048, 400000),
+                                     (32768, 16384, 1800000)])
+def test_gpu_dynamic_window_and_residual_vs_oracle(n, pre, L):
+    from detprocess_amd import OptimumFilterTrigger
+    tmpl, psd, t, x, onsets, extra = _pileup_stream(n, pre, L, seed=21)
+    x32 = x.astype(np.float32)
+    x64 = x32.astype(np.float64)
+    t.update_trace(x64)
+    dmax = float(np.max(t.delta_chi2))
+    g = OptimumFilterTrigger("chanA", FS, tmpl, psd, pre)
+    g.update_trace(x32)
+    fn = lambda d: 50.0 + 0.4 * n * min(1.0, d / dmax)           # window grows with the maximum
+    # ---- dynamic pile-up window (oftrigger.py:78-143, 982-986)
+    ref = t.find_triggers(6.0, dynamic_function=fn)
+    with pytest.raises(ValueError, match="dynamic_threshold_function"):
+        g.find_triggers_once(6.0, dynamic=True)
+    g.find_triggers(6.0, dynamic=True, dynamic_threshold_function=fn)
+    td = g.get_trigger_data()["chanA"]
+    thr = ref["chi2_threshold"]
+    margin = 1e-3 * thr + 4e-5 * dmax
+    clear = [int(i) for i, d in zip(ref["trigger_index"], ref["trigger_delta_chi2"]) if d > 2 * thr + margin]
+    assert set(clear) <= set(td["trigger_index"])
+    assert abs(len(td["trigger_index"]) - len(ref["trigger_index"])) <= max(2, len(ref["trigger_index"]) // 10)
+    ri = dict(zip(ref["trigger_index"].tolist(), ref["trigger_amplitude"]))
+    for i, a, d in zip(td["trigger_index"], td["trigger_amplitude"], td["trigger_delta_chi2"]):
+        if i in ri:
+            assert a == pytest.approx(ri[i], rel=2e-5, abs=2e-5 * np.max(np.abs(t.filtered)))
+    assert td["trigger_pileup_window"] == [0] * len(td["trigger_index"])
+    # ---- residual pass (oftrigger.py:752-845), static window long enough to hide the extras
+    win = n // 2
+    first, second, residual, combined = t.find_triggers_residual(6.0, x64, pileup_window_samples=win)
+    out = g.find_triggers(6.0, pileup_window_samples=win, residual=True, return_trigger_data=True)
+    o_first, o_dchi, o_second, o_res = out
+    gi1 = o_first["chanA"]["trigger_index"]
+    gi2 = o_second["chanA"]["trigger_index"]
+    c1 = {int(i) for i, d in zip(first["trigger_index"], first["trigger_delta_chi2"]) if d > 2 * thr}
+    c2 = {int(i) for i, d in zip(second["trigger_index"], second["trigger_delta_chi2"]) if d > 2 * thr}
+    assert c1 <= set(gi1) and c2 <= set(gi2)
+    if pre == n // 2:
+        assert len(set(gi2) - set(gi1)) >= 1                # the hidden pulses come out
+    assert np.max(np.abs(o_res.astype(np.float64) - residual)) <= 1e-4 * dmax
+    assert np.max(np.abs(o_dchi.astype(np.float64) - t.delta_chi2)) <= 4e-5 * dmax
+    comb = g.get_trigger_data()["chanA"]
+    assert comb["trigger_index"][:len(gi1)] == gi1          # first pass first, new ones appended
+    assert set(comb["trigger_index"]) == set(gi1) | set(gi2)
+    assert len(comb["trigger_index"]) == len(set(comb["trigger_index"]))
+    for key in ("trigger_delta_chi2", "trigger_time", "trigger_amplitude", "trigger_type",
+                "trigger_channel", "trigger_index_chanA"):
+        assert len(comb[key]) == len(comb["trigger_index"]), key
+    # the delta-chi2 trace on the device is the first-pass one again
+    assert np.array_equal(g.get_filtered_delta_chi2(), o_dchi)
+    # ---- saturation veto: with every large pulse "saturated" nothing is subtracted
+    lp = ot.lowpass_50khz(x64, FS)
+    level = 0.3 * float(np.max(lp))
+    f3, s3, r3, comb3 = t.find_triggers_residual(6.0, x64, pileup_window_samples=win, saturation=[level])
+    out3 = g.find_triggers(6.0, pileup_window_samples=win, residual=True,
+                           saturation_amplitudes_LPF_50kHz=[level], return_trigger_data=True)
+    assert np.max(np.abs(out3[3].astype(np.float64) - r3)) <= 1e-4 * dmax
+    big = [int(i) for i in f3["trigger_index"] if np.max(lp[i - n // 4: i + n // 4]) > level]
+    assert big, "the test stream must contain saturated pulses"
+    assert np.max(r3[big]) > 0.5 * np.min(t.delta_chi2[big])       # the vetoed pulses stay
+
+
+@pytest.mark.gpu
+def test_gpu_residual_pass_two_channels_two_amplitudes():
+    """N x M (2 x 2): the pulse table G_ab[z] against the oracle's per-trigger construction."""
+    from detprocess_amd import OptimumFilterTrigger
+    from test_ofnxm import make_csd, make_templates
+    n, pre, L = 4096, 2048, 200000
+    tm = make_templates(n, pre, 2, 2)
+    csd = make_csd(n, 2)
+    t = ot.OFTriggerNxM(FS, tm, csd, pre)
+    rng = np.random.default_rng(6)
+    x = 2e-12 * rng.standard_normal((2, L))
+    for p, a, b in ((20000, 40.0, 10.0), (20500, 4.0, 3.0), (90000, 25.0, -8.0), (150000, 6.0, 30.0)):
+        for c in range(2):
+            x[c, p:p + n] += t.resolution[0] * a * tm[c, 0] + t.resolution[1] * b * tm[c, 1]
+    x32 = x.astype(np.float32)
+    x64 = x32.astype(np.float64)
+    t.update_trace(x64)
+    dmax = float(np.max(t.delta_chi2))
+    g = OptimumFilterTrigger(["A", "B"], FS, tm, csd, pre, trigger_name="AB")
+    g.update_trace(x32)
+    first, second, residual, combined = t.find_triggers_residual(6.0, x64, pileup_window_samples=2000)
+    out = g.find_triggers(6.0, pileup_window_samples=2000, residual=True, return_trigger_data=True)
+    thr = first["chi2_threshold"]
+    c1 = {int(i) for i, d in zip(first["trigger_index"], first["trigger_delta_chi2"]) if d > 2 * thr}
+    assert c1 <= set(out[0]["AB"]["trigger_index"])
+    assert np.max(np.abs(out[3].astype(np.float64) - residual)) <= 2e-4 * dmax
+    c2 = {int(i) for i, d in zip(second["trigger_index"], second["trigger_delta_chi2"]) if d > 2 * thr}
+    assert c2 <= set(out[2]["AB"]["trigger_index"])
