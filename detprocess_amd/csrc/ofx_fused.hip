@@ -92,7 +92,39 @@ static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
 
 // Phase markers: an assembly comment (";ofxphase i") to find the phases in the ISA
 // (hipcc -S; tools/isa_phases.py counts instructions per phase).
+#ifndef OFX_STAMPS
 #define STAMP(i) asm volatile(";ofxphase " #i)
+#else
+// Diagnostic build (-DOFX_STAMPS, tools/phase_timeline.py): every wave writes the shader clock at
+// every phase marker of its first OFX_STAMP_TRACES traces into the buffer passed in place of
+// `xwide` ([workgroup][trace][wave][16]; slot 13: HW_ID, slot 14: XCC_ID) with SCALAR stores --
+// no branch, no exec-mask change, so the scheduling regions of the product build stay as they
+// are -- so that the phases of the two workgroups of a CU can be laid over each other.  No
+// output depends on the stamps.
+#define OFX_STAMP_TRACES 40
+__device__ __forceinline__ void ofx_stamp(unsigned long long* p) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0"
+                 : "=&s"(t) : "s"(p));
+}
+__device__ __forceinline__ void ofx_stamp_id(unsigned long long* p) {
+    unsigned a, b;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\t"
+                 "s_store_dword %0, %2, 0x68\n\ts_store_dword %1, %2, 0x70"
+                 : "=&s"(a), "=&s"(b) : "s"(p));
+}
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        asm volatile(";ofxphase " #i);                                                        \
+        {   /* no branch: traces beyond the last slot keep overwriting it */                  \
+            const int si_ = stamp_it < OFX_STAMP_TRACES - 1 ? stamp_it : OFX_STAMP_TRACES - 1; \
+            unsigned long long* sb_ = stamp_base + (size_t)si_ * (NWAVE * 16);                \
+            ofx_stamp(sb_ + (i));                                                             \
+            if ((i) == 0) ofx_stamp_id(sb_);                                                  \
+            if ((i) == 12) ++stamp_it;                                                        \
+        }                                                                                     \
+    } while (0)
+#endif
 
 struct FusedTabs {
     const float2* t1;     // [5][512] float4 rows of stage-1 twiddle anchors (see T1Anch)
@@ -562,6 +594,18 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     // registers of the current one are dead (after the arg-max), so that its HBM
     // latency hides under the rest of the tail; `have` = d already holds trace b.
     bool have = false;
+#ifdef OFX_STAMPS
+    int stamp_it = 0;
+    unsigned long long* stamp_base;
+    {
+        const size_t off = (((size_t)blockIdx.x * OFX_STAMP_TRACES) * NWAVE +
+                            (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 16;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(xwide) + off * 8;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        stamp_base = reinterpret_cast<unsigned long long*>(((unsigned long long)hi << 32) | lo);
+    }
+#endif
     for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
         float* row = out + (size_t)b * pd.row;
         if (valid && !valid[b]) {
@@ -1125,9 +1169,24 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
         }
         STAMP(11);                               // tail A: max, reductions, arg-max, lowchi2 terms
-        // ... then d and every table value are dead: request the next trace.  Nothing
-        // below waits on vector memory, so the HBM latency hides under the epilogue and
-        // the first stages of the other workgroup.
+        // The row goes out first (search q by thread q), then the next trace is requested:
+        // with the loads issued first, the writer's temporaries shared registers with the load
+        // destinations and the compiler made it wait for all but one of the 64 loads
+        // (s_waitcnt vmcnt(1)) -- the whole HBM latency sat in front of the row write, and
+        // behind it the first barrier of the next trace held the other three waves
+        // (profiles/r02_phase_timeline_before.json: 9.3 k cycles in "tailB").
+        __syncthreads();
+        if (tt < SDX.n_search) {
+            const int q = tt;
+            float lw = 0.0f;
+            for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
+            const OfxRefined* rp = nullptr;
+            if constexpr (FEAT & 1)
+                if (SDX.search[q].interp) rp = &L.ref[q];
+            ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
+        }
+        // d and every table value are dead: request the next trace; its HBM latency hides
+        // under the loop overhead and the first stages of the other workgroup
         if (MULTI && slot_i + 1 < slot_n) {
             load_spec();                         // the spectrum again, for the next slot
         } else {
@@ -1135,23 +1194,14 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             have = (bn < n_traces) && !(valid && !valid[bn]);
             if (have) load_trace(bn);
         }
-        __syncthreads();
-        if (tt == 0) {
-#pragma unroll 1
-            for (int q = 0; q < SDX.n_search; ++q) {
-                float lw = 0.0f;
-                for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
-                const OfxRefined* rp = nullptr;
-                if constexpr (FEAT & 1)
-                    if (SDX.search[q].interp) rp = &L.ref[q];
-                ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
-            }
-        }
         }
 #undef SDX
 #undef TBX
         STAMP(12);                               // tail B: lowchi2 + row write
     }
+#ifdef OFX_STAMPS
+    asm volatile("s_dcache_wb");
+#endif
 }
 
 }  // namespace
@@ -1280,6 +1330,14 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
         OFX_HIP(hipMalloc(&p->d_fused_xwide, (size_t)p->cu_count * WG_PER_CU *
                                                  (NS_MAX - NLOW_MAX) * sizeof(float2)));
     if (grid > n) grid = n;
+#ifdef OFX_STAMPS
+    const size_t stamp_bytes =
+        (size_t)grid * OFX_STAMP_TRACES * NWAVE * 16 * sizeof(unsigned long long);
+    if (p->d_fused_xwide) (void)hipFree(p->d_fused_xwide);
+    p->d_fused_xwide = nullptr;
+    OFX_HIP(hipMalloc(&p->d_fused_xwide, stamp_bytes));
+    OFX_HIP(hipMemset(p->d_fused_xwide, 0, stamp_bytes));
+#endif
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
@@ -1290,6 +1348,17 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
+#ifdef OFX_STAMPS
+    if (const char* f = getenv("OFX_STAMP_FILE")) {
+        OFX_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(stamp_bytes / 8);
+        OFX_HIP(hipMemcpy(h.data(), p->d_fused_xwide, stamp_bytes, hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(f, "wb")) {
+            fwrite(h.data(), 8, h.size(), fp);
+            fclose(fp);
+        }
+    }
+#endif
     return OFX_OK;
 }
 
@@ -1298,6 +1367,13 @@ static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlo
                        const FusedTabs& tabs, const float* d_traces, const uint8_t* d_valid,
                        long long n, float* d_out, hipStream_t st, const FusedSlotArg* d_slots,
                        int nslots, int nstash) {
+#ifdef OFX_QUICK      // development builds: only the headline variant is compiled
+    if (feat == 0 && !MULTI)
+        return launch<0, false>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots,
+                                nstash);
+    ofx_set_error("OFX_QUICK build: only the FEAT = 0 single-slot kernel exists");
+    return OFX_ERR_UNSUPPORTED;
+#endif
 #define OFX_CASE(F)                                                                            \
     case F:                                                                                    \
         return launch<F, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,     \

@@ -1,0 +1,108 @@
+"""Per-phase timeline of k_fused from the diagnostic stamps build.
+   make -C detprocess_amd/csrc variant NAME=stamps EXTRA=-DOFX_STAMPS      (-> gpurun_stamps.so)
+   OFX_LIB=$PWD/gpurun_stamps.so python tools/phase_timeline.py [n_traces] [out.json]
+Runs the headline plan (32768 samples, of1x1_unconstrained) twice -- two workgroups per CU
+(the product configuration) and OFX_DIAG_WGPC=1 (one per CU) -- and reports, per phase of the
+kernel, the mean shader cycles a workgroup spends in it, plus for the paired run how the two
+workgroups of a CU overlap: the share of time both / one / none of them is in a VALU phase."""
+import json, os, subprocess, sys
+import numpy as np
+
+PH = ['loop', 'wait+td', 'F1', 'E1', 'F2', 'E2', 'mid', 'E3', 'I2', 'E4', 'I1', 'tailA', 'tailB']
+VALU = {'F1', 'F2', 'mid', 'I2', 'I1'}            # register-resident arithmetic phases
+NT = 40
+NW = 4
+
+
+def run(n, wgpc, path):
+    env = dict(os.environ, OFX_STAMP_FILE=path)
+    if wgpc == 1:
+        env['OFX_DIAG_WGPC'] = '1'
+    code = f'''
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from detprocess_amd import OFPlan, build_filter, synth, SynthSource
+N=32768; fs=1.25e6; pre=N//2
+tmpl=synth.make_template(N,pre,fs); psd=synth.make_psd(N,fs); ft=build_filter(tmpl,psd,fs,pre)
+gen=SynthSource(N,tmpl,psd,fs,3*ft.ampres,300*ft.ampres,0.5,2000,seed=1)
+x=torch.empty(({n},N),dtype=torch.float32,device='cuda:0'); gen.fill(0,{n},x)
+plan=OFPlan(N,pre,fs,max_batch=8192,engine='fused'); plan.set_filter(0,ft); plan.add_search(0,'delay')
+for _ in range(3): plan.process(x)
+torch.cuda.synchronize()
+'''
+    subprocess.run([sys.executable, '-c', code], env=env, check=True)
+    a = np.fromfile(path, dtype=np.uint64).reshape(-1, NT, NW, 16)
+    return a[:, :, 0, :]          # wave 0 of every workgroup
+
+
+def summarise(a):
+    t = a[:, :, :13].astype(np.int64)
+    ok = (t[:, :, 12] > 0) & (t[:, :, 0] > 0)
+    ok[:, :4] = False                               # warm-up traces
+    d = np.diff(t, axis=2)                          # phase i = stamp i -> stamp i+1
+    nxt = np.zeros_like(t[:, :, 0]); nxt[:, :-1] = t[:, 1:, 0]
+    last = nxt - t[:, :, 12]                        # tail B remainder + loop overhead
+    ok[:, -2:] = False
+    ok &= nxt > 0
+    per = {PH[i + 1]: float(d[:, :, i][ok].mean()) for i in range(12)}
+    per['tailB'] = per.get('tailB', 0.0)
+    per['loop'] = float(last[ok].mean())
+    per['total'] = float((nxt - t[:, :, 0])[ok].mean())
+    return per
+
+
+def overlap(a):
+    """Pairs of workgroups on the same CU (XCC_ID, HW_ID se/sh/cu bits): fraction of the common
+    time span in which 2 / 1 / 0 of them are in a register-arithmetic phase."""
+    t = a[:, :, :13].astype(np.int64)
+    hw = (a[:, 4, 13].astype(np.int64)) & 0xffffffff
+    xcc = a[:, 4, 14].astype(np.int64) & 0xf
+    cu = (xcc << 16) | (hw & 0xff00)              # cu_id[11:8], sh_id[12], se_id[15:13]
+    res = []
+    for key in np.unique(cu):
+        w = np.nonzero(cu == key)[0]
+        if len(w) != 2:
+            continue
+        iv = []
+        for g in w:
+            segs = []
+            for k in range(6, NT - 3):
+                if t[g, k, 12] == 0:
+                    continue
+                for i, name in enumerate(PH[1:]):
+                    if name in VALU:
+                        segs.append((t[g, k, i], t[g, k, i + 1]))
+            iv.append(segs)
+        if not iv[0] or not iv[1]:
+            continue
+        lo = max(iv[0][0][0], iv[1][0][0]); hi = min(iv[0][-1][1], iv[1][-1][1])
+        if hi <= lo:
+            continue
+        ev = []
+        for segs in iv:
+            for s, e in segs:
+                s, e = max(s, lo), min(e, hi)
+                if e > s:
+                    ev += [(s, 1), (e, -1)]
+        ev.sort()
+        cnt, prev, acc = 0, lo, [0, 0, 0]
+        for x, dlt in ev:
+            acc[cnt] += x - prev; prev = x; cnt += dlt
+        acc[cnt] += hi - prev
+        res.append([v / (hi - lo) for v in acc])
+    r = np.asarray(res)
+    return {'pairs': int(len(r)), 'none_in_valu_phase': float(r[:, 0].mean()),
+            'one_in_valu_phase': float(r[:, 1].mean()), 'both_in_valu_phase': float(r[:, 2].mean())}
+
+
+if __name__ == '__main__':
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    dest = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline.json'
+    a2 = run(n, 2, '/tmp/stamps2.bin')
+    a1 = run(n, 1, '/tmp/stamps1.bin')
+    rep = {'cycles_per_phase_2wg_per_cu': summarise(a2), 'cycles_per_phase_1wg_per_cu': summarise(a1),
+           'overlap_2wg': overlap(a2)}
+    json.dump(rep, open(dest, 'w'), indent=1)
+    for k in PH[1:] + ['loop', 'total']:
+        print(f"{k:8s} 2wg {rep['cycles_per_phase_2wg_per_cu'][k]:9.0f}   1wg {rep['cycles_per_phase_1wg_per_cu'][k]:9.0f}")
+    print(rep['overlap_2wg'])
