@@ -80,12 +80,14 @@ __device__ __forceinline__ OfxCand ofx_cand_wave_reduce(OfxCand c) {
 
 // Block reduce; result valid in every thread.  scratch: >= (nthreads/64) OfxCand.
 // tid: this thread's index (pass an opaque copy to keep the address arithmetic local).
+// nwave: waves taking part (default: the whole workgroup; the FUSED kernel passes the waves of
+// one half -- the barrier is still the workgroup's).
 __device__ __forceinline__ OfxCand ofx_cand_block_reduce(OfxCand c, OfxCand* scratch,
-                                                         int tid = -1) {
+                                                         int tid = -1, int nwave = 0) {
     if (tid < 0) tid = threadIdx.x;
     const int lane = tid & (OFX_WAVE - 1);
     const int wave = tid / OFX_WAVE;
-    const int nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
+    if (nwave <= 0) nwave = (blockDim.x + OFX_WAVE - 1) / OFX_WAVE;
     c = ofx_cand_wave_reduce(c);
     __syncthreads();
     if (lane == 0) scratch[wave] = c;

@@ -53,10 +53,29 @@ constexpr int FN = 32768;          // samples
 constexpr int FM = 16384;          // packed complex points
 constexpr int FV = 512;            // virtual threads
 constexpr int FT = FV / VT;        // hardware threads per workgroup
+// PP ("ping-pong", build with -DOFX_PP=1; measured and NOT the product configuration): ONE
+// 512-thread workgroup per CU carries TWO traces, one per half (waves 0-3 / 4-7: the two waves
+// of every SIMD belong to different halves).  The halves run the same program two barriers
+// apart, so that whenever one half is in an LDS exchange the other is in a register-arithmetic
+// phase: the exchange buffer is shared (full size: every exchange is a single pass) and never
+// has two users.  Motivation: with two independent 256-thread workgroups per CU both sit in
+// exchange phases at the same time more than half of the time
+// (profiles/r02_phase_timeline_before.json).  Result (profiles/r02_phase_timeline_pingpong.json):
+// correct (every GPU test passes) but 6 % slower, 14.6 against 15.6 M traces/s -- in lock-step
+// every stall of one half (filter-table latency in the middle step, the reductions of the
+// tail, the wait for the next trace) holds the partner at the next barrier, whereas independent
+// workgroups fill each other's stalls.  Kept as a build option and as the record of that
+// experiment.
+#ifndef OFX_PP
+#define OFX_PP 0
+#endif
+constexpr bool PP = (OFX_PP != 0) && (OFX_VT == 2);
 #ifndef OFX_WGPC
 #define OFX_WGPC OFX_VT
 #endif
-constexpr int WG_PER_CU = OFX_WGPC;    // workgroups resident per CU
+constexpr int WG_PER_CU = PP ? 1 : OFX_WGPC;    // workgroups resident per CU
+constexpr int NHALF = PP ? 2 : 1;               // traces in flight per workgroup
+constexpr int BLOCK_THREADS = FT * NHALF;
 constexpr int NV = 32 * VT;        // complex values per hardware thread
 constexpr int LD1 = 528;           // D1 row stride (elements); 528 = 16 mod 32
 constexpr int LD2 = 17;            // D2 row stride (elements)
@@ -69,18 +88,20 @@ constexpr int NWAVE = FT / OFX_WAVE;
 // buffer (68 KiB per workgroup instead of 136): pass 0 moves the rows of the lower
 // half of the layout (D1: k1 < 16, D2: k_low < 512), pass 1 the upper half.  Values
 // stay complex (ds_write_b64 / ds_read_b64: 2/3 of the LDS cycles of a re/im split).
-constexpr bool SPLIT_EXCHANGE = (WG_PER_CU > 1);
+constexpr bool SPLIT_EXCHANGE = !PP && (WG_PER_CU > 1);
 constexpr int HB1 = 16 * LD1;      // D1 elements per half
 constexpr int HB2 = 512 * LD2;     // D2 elements per half
 
-struct FusedLds {
+struct FusedShared {               // one per workgroup
     float xb[SPLIT_EXCHANGE ? XBUF_ELEMS : 2 * XBUF_ELEMS];   // exchange buffer / lag dump
     cpx t2[512];                   //  4,096 B   w_512^{n3 k2}, index k2*16+n3
+};
+struct FusedLds {                  // one per trace in flight (per half)
     cpx xlow[NLOW_MAX + 8];        //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
     float tdred[OFX_MAX_TDWIN][4][NWAVE];   // time-domain window partials
     OfxCand cand[NWAVE];
-    OfxCand sres[OFX_MAX_SEARCHES];
+    OfxCand wc[OFX_MAX_SEARCHES][NWAVE];    // per-wave winners of the windowed searches
     OfxCand fin[OFX_MAX_SEARCHES];          // resolved fit per search
     float lowp[OFX_MAX_SEARCHES][NWAVE];    // low-frequency chi2 per wave
     float bcast[8];
@@ -88,7 +109,8 @@ struct FusedLds {
     float nb[OFX_MAX_SEARCHES][2];          // amplitudes next to the winner (interpolation)
     OfxRefined ref[OFX_MAX_SEARCHES];       // refined fits
 };
-static_assert(sizeof(FusedLds) * WG_PER_CU <= 160 * 1024, "LDS budget");
+constexpr size_t FUSED_LDS_BYTES = sizeof(FusedShared) + NHALF * sizeof(FusedLds);
+static_assert(FUSED_LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
 
 // Phase markers: an assembly comment (";ofxphase i") to find the phases in the ISA
 // (hipcc -S; tools/isa_phases.py counts instructions per phase).
@@ -409,7 +431,7 @@ struct Roles {
 //        it.  Slots come from `slots[0 .. nslots)`; sd / tabs then only carry the shared
 //        twiddle tables.  Not MULTI: the one slot is (sd, tabs), as kernel arguments.
 template <int FEAT, bool MULTI>
-__global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
+__global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) void k_fused(OfxPlanDev pd, OfxSlotDev sd, FusedTabs tabs,
                                                  const float* __restrict__ traces,
                                                  const uint8_t* __restrict__ valid,
                                                  long long n_traces, float* __restrict__ out,
@@ -418,14 +440,24 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                                                  float2* __restrict__ xwide, int nstash) {
     constexpr bool WIDE = (FEAT & 8) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    FusedLds& L = *reinterpret_cast<FusedLds*>(smem_raw);
-    const int tid = threadIdx.x;
+    // half: which of the workgroup's traces this wave works on (wave-uniform); wg: index of
+    // that trace slot in the grid (scratch areas, stamps); tid / wave: index within the half
+    const int half = PP ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x / FT)) : 0;
+    const int wg = (int)blockIdx.x * NHALF + half;
+    FusedShared& SH = *reinterpret_cast<FusedShared*>(smem_raw);
+    FusedLds& L = reinterpret_cast<FusedLds*>(smem_raw + sizeof(FusedShared))[half];
+    const int tid = PP ? (int)(threadIdx.x & (FT - 1)) : (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    // slot barrier of the ping-pong schedule inside a register-arithmetic phase (see exchange)
+#define PPB()                                  \
+    do {                                       \
+        if constexpr (PP) __syncthreads();     \
+    } while (0)
     const int pre = pd.pre;
     const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 5 * 512 * 16);
     const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 512 * 8);
 
-    for (int i = tid; i < 512; i += FT) L.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
+    for (int i = tid; i < 512; i += FT) SH.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
 
     const size_t ev_stride = (size_t)pd.n_channels * FN;
     cpx d[NV];
@@ -433,11 +465,21 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     // LDS exchange of the NV values of a thread.  widx / ridx map (role h, value j) to
     // an element index of the full layout; wpass / rpass give the half (0 / 1) that
     // element belongs to, hb the elements per half.
+    //
+    // PP: the buffer is shared by the two halves of the workgroup, which run the same program
+    // two barriers apart.  An exchange is  [B] writes [B] reads [B]  and every arithmetic phase
+    // between two exchanges holds exactly one barrier (PPB) -- so while this half writes / reads,
+    // the partner is in the first / second part of an arithmetic phase, and the other way
+    // round: the buffer has one user at a time and LDS time overlaps VALU time by construction.
+    // Rule for every use of SH.xb: at most two barrier-delimited segments long, and at least
+    // one barrier between the end of one use and the start of the next.  Every barrier is
+    // executed by all eight waves the same number of times: no barrier sits under a condition
+    // that depends on the half or on the data.
     auto exchange = [&](auto widx, auto wpass, auto ridx, auto rpass, int hb) {
 #ifdef ABL_NOEXCH
         return;
 #endif
-        cpx* xc = reinterpret_cast<cpx*>(L.xb);
+        cpx* xc = reinterpret_cast<cpx*>(SH.xb);
         if constexpr (!SPLIT_EXCHANGE) {
             __syncthreads();                   // earlier readers of xb are done
 #pragma unroll
@@ -449,6 +491,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             for (int h = 0; h < VT; ++h)
 #pragma unroll
                 for (int j = 0; j < 32; ++j) d[32 * h + j] = xc[ridx(h, j)];
+            PPB();                             // reads done: the partner may write
         } else {
             cpx nd[NV];
 #pragma unroll
@@ -481,7 +524,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     // scalar branch (the empty asm keeps the compiler from turning them into selects).
     constexpr bool DIAG_D1 = (VT == 1) && SPLIT_EXCHANGE;
     auto exchange_d1 = [&](const Roles& R, bool e4) {
-        cpx* xc = reinterpret_cast<cpx*>(L.xb);
+        cpx* xc = reinterpret_cast<cpx*>(SH.xb);
         const int hw = __builtin_amdgcn_readfirstlane(R.vt >> 8);
         const int rowb = (R.k1u & 15) * LD1 + R.n3u;       // (k1u, n3u) side, + 16 n2
         cpx lo[16], hi[16];                                 // new values, halves 0 / 1
@@ -571,7 +614,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 
     // MULTI: the spectrum of the current trace, [value j][thread] in this workgroup's area.
     const __amdgpu_buffer_rsrc_t rspec =
-        make_rsrc(spec + (MULTI ? (size_t)blockIdx.x * NV * FT : 0), NV * FT * 8);
+        make_rsrc(spec + (MULTI ? (size_t)wg * NV * FT : 0), NV * FT * 8);
     auto store_spec = [&]() __attribute__((always_inline)) {
         int tl = tid;
         asm volatile("" : "+v"(tl));
@@ -598,20 +641,41 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
     int stamp_it = 0;
     unsigned long long* stamp_base;
     {
-        const size_t off = (((size_t)blockIdx.x * OFX_STAMP_TRACES) * NWAVE +
-                            (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 16;
+        const size_t off = (((size_t)wg * OFX_STAMP_TRACES) * NWAVE +
+                            (size_t)__builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & (NWAVE - 1))) * 16;
         const unsigned long long a = reinterpret_cast<unsigned long long>(xwide) + off * 8;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
         stamp_base = reinterpret_cast<unsigned long long*>(((unsigned long long)hi << 32) | lo);
     }
 #endif
-    for (long long b = blockIdx.x; b < n_traces; b += gridDim.x) {
+    // PP: the second half starts two barriers late (and the first ends two barriers late)
+    if constexpr (PP) {
+        if (half == 1) {
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+    // Trace slots are handed out in groups of NHALF; a half whose slot lies beyond the batch
+    // (odd batch) works on the last trace again and writes nothing, and an event flagged
+    // invalid runs through the whole pipeline and gets the sentinel row at the end: every wave
+    // executes the same sequence of barriers whatever the data.
+    const long long stride = (long long)gridDim.x * NHALF;
+    for (long long b0 = (long long)blockIdx.x * NHALF; b0 < n_traces; b0 += stride) {
+        const bool dummy = (b0 + half >= n_traces);
+        const long long b = dummy ? n_traces - 1 : b0 + half;
         float* row = out + (size_t)b * pd.row;
-        if (valid && !valid[b]) {
+        const bool skip = dummy || (valid && !valid[b]);     // wave-uniform
+        // (the sentinel row goes out first -- nothing else is written for such an event; with
+        // this loop after the pipeline, next to the prefetched registers of the following
+        // trace, the allocator spilled the whole data array)
+        if (skip && !dummy)
             for (int j = tid; j < pd.row; j += FT) row[j] = OFX_SENTINEL;
-            have = false;
-            continue;
+        if constexpr (!PP) {       // independent workgroups: an invalid event is simply skipped
+            if (skip) {
+                have = false;
+                continue;
+            }
         }
         // Roles are re-derived from an opaque copy of tid every trace so that the LDS
         // address arithmetic stays next to its use (LICM would hoist and spill it).
@@ -691,7 +755,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                 }
             }
             __syncthreads();
-            if (tid < pd.n_tdwin) {                      // one thread finalises one window
+            if (tid < pd.n_tdwin && !skip) {             // one thread finalises one window
                 const int w = tid;
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float S = 0.f, SQ = 0.f, MX = -INFINITY, MN = INFINITY;
@@ -753,12 +817,13 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         STAMP(3);                                // E1
         // ---------------------------------------------------------------- F2
         dft<32, -1, NV, 0>(d);
+        PPB();
         if constexpr (VT == 2) dft<32, -1, NV, 32 * (VT - 1)>(d);
 #pragma unroll
         for (int h = 0; h < VT; ++h)
 #pragma unroll
             for (int k2 = 1; k2 < 32; ++k2)
-                d[32 * h + k2] = cmul(d[32 * h + k2], L.t2[k2 * 16 + RR(h).n3u]);
+                d[32 * h + k2] = cmul(d[32 * h + k2], SH.t2[k2 * 16 + RR(h).n3u]);
         STAMP(4);                                // F2
         exchange([&](int h, int j) { return RR(h).e2w(j); }, [](int, int j) { return j >> 4; },
                  [&](int h, int j) { return RR(h).e2r(j); }, [](int, int j) { return j >> 4; },
@@ -783,7 +848,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         // ------------------------------------------- F3, middle, I3 (registers)
         const MidRsrc rmid = {make_rsrc(TBX.midW, 16 * 512 * 16),
                               make_rsrc(TBX.midG, 16 * 512 * 8),
-                              make_rsrc(xwide + (WIDE ? (size_t)blockIdx.x * (NS_MAX - NLOW_MAX) : 0),
+                              make_rsrc(xwide + (WIDE ? (size_t)wg * (NS_MAX - NLOW_MAX) : 0),
                                         (WIDE && slot_i == 0) ? (nstash - NLOW_MAX) * 8 : 0)};
         cpx chi2v = mk(0.0f, 0.0f);
         constexpr bool STAGE_B = (VT == 1) && SPLIT_EXCHANGE;
@@ -794,7 +859,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             }
             const cpx a8 = d[8];
             if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
-            cpx* xs = reinterpret_cast<cpx*>(L.xb) + tl;
+            cpx* xs = reinterpret_cast<cpx*>(SH.xb) + tl;
             const cpx tb = buf_ld2(rtb, tl * 8, 0);
             const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
             __syncthreads();                   // every E2 read is done: the buffer is free
@@ -820,6 +885,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             dft<16, +1, NV, 0>(d);
             dft<16, +1, NV, 16>(d);
         }
+        PPB();
         if constexpr (VT == 2) {
             constexpr int O = 32 * (VT - 1);
             if constexpr (!MULTI) {
@@ -846,8 +912,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         for (int h = 0; h < VT; ++h)
 #pragma unroll
             for (int k2 = 1; k2 < 32; ++k2)
-                d[32 * h + k2] = cmulc(d[32 * h + k2], L.t2[k2 * 16 + QQ(h).n3u]);
+                d[32 * h + k2] = cmulc(d[32 * h + k2], SH.t2[k2 * 16 + QQ(h).n3u]);
         dft<32, +1, NV, 0>(d);
+        PPB();
         if constexpr (VT == 2) dft<32, +1, NV, 32 * (VT - 1)>(d);
         STAMP(8);                                // I2
         {
@@ -881,6 +948,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 #pragma unroll
             for (int j = 0; j < NV; ++j) acc += d[j].x + d[j].y;
             if (acc == 1.2345f) row[0] = acc;
+            PPB();
             continue;
         }
 #endif
@@ -974,12 +1042,14 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     }
                 }
             }
-            fullbest = ofx_cand_block_reduce(fullbest, L.cand, tt);
+            fullbest = ofx_cand_block_reduce(fullbest, L.cand, tt, NWAVE);
         }
 
-        // windowed / outside-window fits scan the lag dump
+        // windowed / outside-window fits scan the lag dump: one use of the exchange buffer,
+        // two barrier-delimited segments (dump | scans of every windowed search, each wave
+        // keeping its winner per search in L.wc; the waves' winners are merged by resolve)
         if constexpr (FEAT & 1) {
-            if (tt < OFX_MAX_SEARCHES) L.sres[tt] = ofx_cand_none();
+            if (lane_t < OFX_MAX_SEARCHES) L.wc[lane_t][wave_t] = ofx_cand_none();
             constexpr int NPASS = SPLIT_EXCHANGE ? 2 : 1;   // SPLIT: even lags, then odd
             for (int e = 0; e < NPASS; ++e) {
                 __syncthreads();
@@ -989,9 +1059,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     for (int n1 = 0; n1 < 32; ++n1) {
                         const int m = 512 * n1 + tt + FT * h;
                         if constexpr (SPLIT_EXCHANGE) {
-                            L.xb[m] = e ? d[32 * h + n1].y : d[32 * h + n1].x;   // A(2m+e)
+                            SH.xb[m] = e ? d[32 * h + n1].y : d[32 * h + n1].x;   // A(2m+e)
                         } else {
-                            reinterpret_cast<cpx*>(L.xb)[m] = d[32 * h + n1];    // A(2m), A(2m+1)
+                            reinterpret_cast<cpx*>(SH.xb)[m] = d[32 * h + n1];    // A(2m), A(2m+1)
                         }
                     }
                 __syncthreads();
@@ -1005,9 +1075,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                         for (int i = i0 + tt; i < i1; i += FT) {
                             const int n = (i - pre) & (FN - 1);
                             if constexpr (SPLIT_EXCHANGE) {
-                                if ((n & 1) == e) ofx_cand_take(c, L.xb[n >> 1], i);
+                                if ((n & 1) == e) ofx_cand_take(c, SH.xb[n >> 1], i);
                             } else {
-                                ofx_cand_take(c, L.xb[n], i);
+                                ofx_cand_take(c, SH.xb[n], i);
                             }
                         }
                     };
@@ -1017,8 +1087,9 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     } else {
                         scan(sq.lo, sq.hi);
                     }
-                    c = ofx_cand_block_reduce(c, L.cand, tt);
-                    if (tt == 0 && ofx_cand_better(c.key, c.idx, L.sres[q])) L.sres[q] = c;
+                    c = ofx_cand_wave_reduce(c);
+                    if (lane_t == 0 && ofx_cand_better(c.key, c.idx, L.wc[q][wave_t]))
+                        L.wc[q][wave_t] = c;
                 }
             }
             __syncthreads();
@@ -1027,7 +1098,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         // psd_amp bands from the stashed 2 X_k (LDS below NLOW_MAX, the global stash above);
         // one wave per band
         const __amdgpu_buffer_rsrc_t rxw =
-            make_rsrc(xwide + (WIDE ? (size_t)blockIdx.x * (NS_MAX - NLOW_MAX) : 0),
+            make_rsrc(xwide + (WIDE ? (size_t)wg * (NS_MAX - NLOW_MAX) : 0),
                       WIDE ? (nstash - NLOW_MAX) * 8 : 0);
         if (pd.n_bands > 0 && slot_i == 0) {
             const float cpsd = 0.25f / ((float)FN * pd.fs);      // (2 X)^2 / 4 / (N fs)
@@ -1041,7 +1112,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
                     acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
                 }
                 acc = ofx_wave_sum(acc);
-                if (lane_t == 0) row[pd.band[i].out_off] = acc / (float)(hi - lo);
+                if (lane_t == 0 && !skip) row[pd.band[i].out_off] = acc / (float)(hi - lo);
             }
         }
 
@@ -1057,8 +1128,14 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
             } else if (full) {
                 best = fullbest;
             } else {
-                if constexpr (FEAT & 1) best = L.sres[q];
-                else best = ofx_cand_none();
+                best = ofx_cand_none();
+                if constexpr (FEAT & 1) {
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) {
+                        const OfxCand o = L.wc[q][w];
+                        if (ofx_cand_better(o.key, o.idx, best)) best = o;
+                    }
+                }
             }
             return best;
         };
@@ -1176,7 +1253,7 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         // behind it the first barrier of the next trace held the other three waves
         // (profiles/r02_phase_timeline_before.json: 9.3 k cycles in "tailB").
         __syncthreads();
-        if (tt < SDX.n_search) {
+        if (tt < SDX.n_search && !skip) {
             const int q = tt;
             float lw = 0.0f;
             for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
@@ -1190,8 +1267,8 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
         if (MULTI && slot_i + 1 < slot_n) {
             load_spec();                         // the spectrum again, for the next slot
         } else {
-            const long long bn = b + gridDim.x;
-            have = (bn < n_traces) && !(valid && !valid[bn]);
+            const long long bn = b0 + stride + half;
+            have = bn < n_traces;
             if (have) load_trace(bn);
         }
         }
@@ -1199,6 +1276,13 @@ __global__ __launch_bounds__(FT, (FT / 256) * WG_PER_CU) void k_fused(OfxPlanDev
 #undef TBX
         STAMP(12);                               // tail B: lowchi2 + row write
     }
+    if constexpr (PP) {
+        if (half == 0) {
+            __syncthreads();
+            __syncthreads();
+        }
+    }
+#undef PPB
 #ifdef OFX_STAMPS
     asm volatile("s_dcache_wb");
 #endif
@@ -1306,18 +1390,18 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
                   hipStream_t st, const FusedSlotArg* d_slots, int nslots, int nstash) {
     // (100 KiB covers the diagnostic one-workgroup-per-CU launch below as well)
     OFX_LDS_ATTR_ONCE((k_fused<FEAT, MULTI>),
-                      sizeof(FusedLds) > 100 * 1024 ? sizeof(FusedLds) : 100 * 1024);
+                      FUSED_LDS_BYTES > 100 * 1024 ? FUSED_LDS_BYTES : 100 * 1024);
     long long grid = (long long)p->cu_count * WG_PER_CU;
-    size_t lds_bytes = sizeof(FusedLds);
+    size_t lds_bytes = FUSED_LDS_BYTES;
     // diagnostic: OFX_DIAG_WGPC=1 runs one workgroup per CU (uncontended phase times)
     static const int diag_wgpc = getenv("OFX_DIAG_WGPC") ? atoi(getenv("OFX_DIAG_WGPC")) : 0;
-    if (diag_wgpc == 1) {
+    if (diag_wgpc == 1 && !PP) {
         grid = p->cu_count;
         lds_bytes = 100 * 1024;
     }
     if (MULTI) {
         // per-workgroup spectrum scratch (sized for the full grid, allocated once)
-        const size_t need = (size_t)p->cu_count * WG_PER_CU * NV * FT * sizeof(float2);
+        const size_t need = (size_t)p->cu_count * WG_PER_CU * NHALF * NV * FT * sizeof(float2);
         if (p->fused_spec_bytes < need) {
             if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
             p->d_fused_spec = nullptr;
@@ -1327,12 +1411,12 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
         }
     }
     if ((FEAT & 8) && !p->d_fused_xwide)   // per-workgroup stash of the bins 512 .. NS_MAX-1
-        OFX_HIP(hipMalloc(&p->d_fused_xwide, (size_t)p->cu_count * WG_PER_CU *
+        OFX_HIP(hipMalloc(&p->d_fused_xwide, (size_t)p->cu_count * WG_PER_CU * NHALF *
                                                  (NS_MAX - NLOW_MAX) * sizeof(float2)));
-    if (grid > n) grid = n;
+    if (grid * NHALF > n) grid = (n + NHALF - 1) / NHALF;
 #ifdef OFX_STAMPS
     const size_t stamp_bytes =
-        (size_t)grid * OFX_STAMP_TRACES * NWAVE * 16 * sizeof(unsigned long long);
+        (size_t)grid * NHALF * OFX_STAMP_TRACES * NWAVE * 16 * sizeof(unsigned long long);
     if (p->d_fused_xwide) (void)hipFree(p->d_fused_xwide);
     p->d_fused_xwide = nullptr;
     OFX_HIP(hipMalloc(&p->d_fused_xwide, stamp_bytes));
@@ -1341,7 +1425,7 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_fused<FEAT, MULTI>), dim3((unsigned)grid), dim3(FT), lds_bytes, st, pd,
+    hipLaunchKernelGGL((k_fused<FEAT, MULTI>), dim3((unsigned)grid), dim3(BLOCK_THREADS), lds_bytes, st, pd,
                        sd, tabs, d_traces, d_valid, n, d_out, d_slots, nslots,
                        reinterpret_cast<float2*>(p->d_fused_spec),
                        reinterpret_cast<float2*>(p->d_fused_xwide), nstash);
@@ -1373,7 +1457,7 @@ static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlo
                                 nstash);
     ofx_set_error("OFX_QUICK build: only the FEAT = 0 single-slot kernel exists");
     return OFX_ERR_UNSUPPORTED;
-#endif
+#else
 #define OFX_CASE(F)                                                                            \
     case F:                                                                                    \
         return launch<F, MULTI>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,     \
@@ -1386,6 +1470,7 @@ static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlo
                                           d_slots, nslots, nstash);
     }
 #undef OFX_CASE
+#endif
 }
 
 // One launch per call: a plan with several filter slots runs them all on the shared
