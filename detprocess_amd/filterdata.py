@@ -190,6 +190,81 @@ class FilterData:
                 if not k.endswith(("_metadata", "_inds")):
                     print(f"   {k}: {getattr(v, 'shape', '')}")
 
+    # ------------------------------------------------------------------ HDF5
+    @staticmethod
+    def _h5py():
+        try:
+            import h5py
+        except ImportError as exc:
+            raise ImportError(
+                "ERROR: h5py is required for HDF5 filter files (detprocess writes them through "
+                "pytesio's FilterH5IO, filterdata.py:218-246, 270-300).  It is not installed in "
+                "this environment: use save_npz / load_npz, or install h5py.") from exc
+        return h5py
+
+    def load_hdf5(self, file_name, overwrite=True):
+        """filterdata.py:218-246.  Layout read: one group per channel; a parameter is either a
+        dataset (array, its attributes = the ``<name>_metadata`` dictionary, with an optional
+        sibling dataset ``<name>_inds``) or a pandas fixed-format node (a group holding
+        ``values`` and ``index`` datasets -- how a 1-D template / psd stored as ``pd.Series``
+        lands in the file): the index becomes ``<name>_inds``.  The authoritative layout lives
+        in pytesio (absent from the reference tree and from this image), so this reader is
+        checked against files written by ``save_hdf5`` only."""
+        h5py = self._h5py()
+        data = {}
+        with h5py.File(file_name, "r") as f:
+            for chan in f:
+                grp = f[chan]
+                if not isinstance(grp, h5py.Group):
+                    continue
+                d = data.setdefault(chan, {})
+                for name, node in grp.items():
+                    meta = {k: (v.item() if hasattr(v, "item") and np.ndim(v) == 0 else v)
+                            for k, v in node.attrs.items()
+                            if not k.startswith(("pandas_", "CLASS", "VERSION", "TITLE"))}
+                    if isinstance(node, h5py.Group):
+                        if "values" not in node:
+                            continue
+                        d[name] = np.asarray(node["values"])
+                        if "index" in node:
+                            d[name + "_inds"] = np.asarray(node["index"])
+                    else:
+                        d[name] = np.asarray(node)
+                    if meta and not name.endswith("_inds"):
+                        d[name + "_metadata"] = meta
+        self.set_data(data, overwrite=overwrite)
+
+    def save_hdf5(self, file_name, overwrite=False):
+        """filterdata.py:270-300: one group per channel, one dataset per array, metadata as
+        attributes (see load_hdf5 for the caveat on the layout)."""
+        h5py = self._h5py()
+        with h5py.File(file_name, "a") as f:
+            for chan, d in self._filter_data.items():
+                grp = f.require_group(chan)
+                for name, val in d.items():
+                    if name.endswith("_metadata"):
+                        continue
+                    if name in grp:
+                        if not overwrite:
+                            continue
+                        del grp[name]
+                    ds = grp.create_dataset(name, data=np.asarray(val))
+                    for k, v in d.get(name + "_metadata", {}).items():
+                        if v is not None:
+                            ds.attrs[k] = v
+
+    def set_data(self, data, overwrite=False):
+        """filterdata.py:248-268."""
+        if not isinstance(data, dict):
+            raise ValueError("ERROR: filter data should be a dictionary!")
+        for key, item in data.items():
+            if key not in self._filter_data:
+                self._filter_data[key] = item
+                continue
+            for par_name, value in item.items():
+                if overwrite or par_name not in self._filter_data[key]:
+                    self._filter_data[key][par_name] = value
+
     # -------------------------------------------------------------- npz carry
     def save_npz(self, file_name):
         flat = {}

@@ -3,17 +3,18 @@
 The reference dumps the accumulated rows as ``<group>/<prefix>_<series>_F####.hdf5`` through
 ``vaex.from_pandas(...).export_hdf5`` whenever the memory limit is hit and at the end
 (features.py:584-629; group directory ``<prefix>_I<facility>_D<yyyymmdd>_T<hhmmss>`` and prefix
-rules features.py:1030-1082, 494-510).  vaex and h5py are not part of this engine; the same
-columns are written as an Arrow IPC file (``.arrow``, opened by ``vaex.open`` as a
-memory-mapped table exactly like its HDF5 files) or as Parquet.  ``vx.open(path).export_hdf5``
-gives the reference's byte format where that is required.
+rules features.py:1030-1082, 494-510).  vaex is not part of this engine; the same columns are
+written as an Arrow IPC file (``.arrow``, opened by ``vaex.open`` as a memory-mapped table
+exactly like its HDF5 files), as Parquet, or -- when h5py is installed -- as ``.hdf5`` in the
+column layout of vaex's own files (``/table/columns/<name>/data``), so that tools globbing for
+``*_F####.hdf5`` find the dumps.
 """
 
 import os
 import stat
 from datetime import datetime
 
-FORMATS = ("arrow", "parquet")
+FORMATS = ("arrow", "parquet", "hdf5")
 
 
 def feature_prefix(processing_id=None, restricted=False, calib=False):
@@ -70,7 +71,9 @@ class FeatureWriter:
             table = pa.Table.from_pandas(feature_df.reset_index(drop=True),
                                          preserve_index=False)
         name = f"{self._base}_F{str(self._dump).zfill(4)}.{self._fmt}"
-        if self._fmt == "arrow":
+        if self._fmt == "hdf5":
+            _write_vaex_hdf5(name, table)
+        elif self._fmt == "arrow":
             with pa.OSFile(name, "wb") as sink, pa.ipc.new_file(sink, table.schema) as writer:
                 writer.write_table(table)
         else:
@@ -81,9 +84,61 @@ class FeatureWriter:
         return name
 
 
+def _h5py():
+    try:
+        import h5py
+    except ImportError as exc:
+        raise ImportError("ERROR: the 'hdf5' feature-file format needs h5py, which is not "
+                          "installed here; use fmt='arrow' or fmt='parquet'") from exc
+    return h5py
+
+
+def _write_vaex_hdf5(name, table):
+    """The layout ``vaex.DataFrame.export_hdf5`` produces for numeric and string columns
+    (features.py:612-616): /table (attr type='table') / columns / <column> / data; strings as
+    Arrow-style ``data`` (bytes) + ``indices`` (int64 offsets) with dtype attributes."""
+    import numpy as np
+    h5py = _h5py()
+    with h5py.File(name, "w") as f:
+        tab = f.require_group("table")
+        tab.attrs["type"] = "table"
+        cols = tab.require_group("columns")
+        for i, col in enumerate(table.column_names):
+            arr = table.column(col).to_numpy(zero_copy_only=False)
+            g = cols.require_group(col)
+            g.attrs["_order"] = i
+            if arr.dtype.kind in "OUS":
+                raw = [str(x).encode("utf8") for x in arr]
+                off = np.zeros(len(raw) + 1, dtype=np.int64)
+                np.cumsum([len(x) for x in raw], out=off[1:])
+                g.attrs["type"] = "column"
+                d = g.create_dataset("data", data=np.frombuffer(b"".join(raw), dtype=np.uint8))
+                d.attrs["dtype"] = "str"
+                d.attrs["dtype_item"] = "utf8"
+                g.create_dataset("indices", data=off)
+            else:
+                g.attrs["type"] = "column"
+                g.create_dataset("data", data=arr)
+
+
 def read_features(file_name):
     """Read one dump back as a pandas DataFrame."""
     import pyarrow as pa
+    if file_name.endswith(".hdf5"):
+        import numpy as np
+        import pandas as pd
+        h5py = _h5py()
+        out = {}
+        with h5py.File(file_name, "r") as f:
+            cols = f["table/columns"]
+            for col in sorted(cols, key=lambda c: cols[c].attrs.get("_order", 0)):
+                g = cols[col]
+                if "indices" in g:
+                    raw, off = bytes(np.asarray(g["data"])), np.asarray(g["indices"])
+                    out[col] = [raw[off[i]:off[i + 1]].decode("utf8") for i in range(len(off) - 1)]
+                else:
+                    out[col] = np.asarray(g["data"])
+        return pd.DataFrame(out)
     if file_name.endswith(".parquet"):
         import pyarrow.parquet as pq
         return pq.read_table(file_name).to_pandas()
