@@ -142,6 +142,9 @@ __device__ __forceinline__ void stages(cpx (&y)[TOT]) {
 // Operates on x[OFF .. OFF+R) of an array of TOT registers.
 template <int R, int DIR, int TOT = R, int OFF = 0>
 __device__ __forceinline__ void dft(cpx (&x)[TOT]) {
+#ifdef ABL_NOFFT      // diagnostic: no butterflies (what the exchanges and the tail cost alone)
+    return;
+#endif
     constexpr int bits = ilog2(R);
     stages<R, TOT, OFF, 2, DIR>(x);
     cpx t[R];

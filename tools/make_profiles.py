@@ -16,20 +16,8 @@ def counter(dirname, name):
     v = sorted(tot.values())
     return (sum(v) / len(v), len(v)) if v else (None, 0)
 
-# 1. kernel stats
-for f in glob.glob(f"{P}/stats/**/*kernel_stats.csv", recursive=True):
-    rows = list(csv.reader(open(f)))
-    with open(f"{OUT}/{tag}_bench_kernel_stats.csv", "w", newline="") as o:
-        csv.writer(o).writerows(rows)
-    for r in rows[1:]:
-        if KERNEL in r[0]:
-            print("kernel stats:", r[0][:60], r[1:5])
-line = [l for l in open(f"{P}/stats.log") if l.startswith('{"metric"')]
-if line:
-    open(f"{OUT}/{tag}_bench_line.json", "w").write(line[-1])
-# 2./3. traffic
-fetch, nf = counter("pmc_FETCH_SIZE", "FETCH_SIZE")
-write, nw = counter("pmc_WRITE_SIZE", "WRITE_SIZE")
+ALG_C = {1: 131088, 2: 131112, 3: 131280}
+TPL = {1: 1048576, 2: 1048576, 3: 262144}          # traces per launch (config 3: one channel plan)
 cal, nc = counter("cal_FETCH_SIZE", "FETCH_SIZE")
 corr = 2.0
 note = "gfx950 x2 (MI355X_MICROARCH.md, HBM section)"
@@ -38,15 +26,36 @@ if cal:
     note = (f"calibrated on the load-only build of the same kernel (same 8 B/lane access pattern, known "
             f"131072 B/trace): FETCH_SIZE reads {cal * 1024 / TRACES:.0f} B/trace -> factor {corr:.3f} "
             f"(the guide's gfx950 factor for 16 B/lane streams is 2)")
-hbm = fetch * 1024.0 * corr + write * 1024.0
-json.dump({"round": rnd,
-           "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
-           "kernel": "k_fused<0,false>", "engine": "fused", "traces_per_launch": TRACES,
-           "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
-           "fetch_correction": corr, "correction": note,
-           "hbm_bytes_per_launch": hbm, "hbm_bytes_per_trace": hbm / TRACES,
-           "algorithmic_bytes_per_trace": ALG}, open(f"{OUT}/{tag}_traffic.json", "w"), indent=1)
-print("traffic B/trace:", hbm / TRACES, "corr", corr)
+for c in (1, 2, 3):
+    # 1. kernel stats
+    for f in glob.glob(f"{P}/stats_c{c}/**/*kernel_stats.csv", recursive=True):
+        rows = list(csv.reader(open(f)))
+        name = f"{OUT}/{tag}_bench_kernel_stats.csv" if c == 1 else f"{OUT}/{tag}_bench_config{c}_kernel_stats.csv"
+        with open(name, "w", newline="") as o:
+            csv.writer(o).writerows(rows)
+        for r in rows[1:]:
+            if KERNEL in r[0]:
+                print(f"config {c} kernel stats:", r[0][:70], r[1:5])
+    if os.path.exists(f"{P}/stats_c{c}.log"):
+        line = [l for l in open(f"{P}/stats_c{c}.log") if l.startswith('{"metric"')]
+        if line:
+            open(f"{OUT}/{tag}_bench_line.json" if c == 1 else f"{OUT}/{tag}_bench_config{c}_line.json",
+                 "w").write(line[-1])
+    # 2./3. traffic
+    fetch, nf = counter(f"pmc_FETCH_SIZE_c{c}", "FETCH_SIZE")
+    write, nw = counter(f"pmc_WRITE_SIZE_c{c}", "WRITE_SIZE")
+    if fetch is None or write is None:
+        continue
+    hbm = fetch * 1024.0 * corr + write * 1024.0
+    json.dump({"round": rnd, "workload": f"config{c}",
+               "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --config {c} --steps 2 --warmup 1 --no-cpu-baseline",
+               "kernel": "k_fused (every launch of the pass averaged)", "engine": "fused", "traces_per_launch": TPL[c],
+               "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write,
+               "fetch_correction": corr, "correction": note,
+               "hbm_bytes_per_launch": hbm, "hbm_bytes_per_trace": hbm / TPL[c],
+               "algorithmic_bytes_per_trace": ALG_C[c]},
+              open(f"{OUT}/{tag}_traffic.json" if c == 1 else f"{OUT}/{tag}_traffic_config{c}.json", "w"), indent=1)
+    print(f"config {c} traffic B/trace:", hbm / TPL[c], "corr", corr)
 # 4. SQ counters per trace
 sq = {}
 for d in ("sq_1", "sq_2"):
