@@ -166,7 +166,8 @@ struct ofx_plan {
     size_t adc_elems = 0;
     long long* d_trig = nullptr;
     size_t trig_elems = 0;
-    void* d_lds_tw = nullptr;            // LDS engine: twiddle table exp(-2 pi i j / N), slot table
+    void* d_lds_tw = nullptr;            // LDS engine: per-stage twiddle tables, slot table
+    int lds_tw_level = 0;                // ... and the table level they were built for
     void* d_lds_slots = nullptr;
     void* d_lds_pos = nullptr;           // ... per-slot pair tables (LdsPair)
     void* d_lds_spec = nullptr;          // ... per-workgroup spectrum scratch (several slots)

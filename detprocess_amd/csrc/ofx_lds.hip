@@ -43,6 +43,7 @@ struct LdsGeom {
     int fac[LDS_MAX_FAC];
     unsigned magic[LDS_MAX_FAC];   // floor(2^32 / stride) + 1 per stage: b / stride = umulhi(b, magic)
     int toff[LDS_MAX_FAC];         // offset of the stage's twiddles W_L^j, j < stride, in the LDS table
+    int vlow;                      // low bins of V kept in LDS (a multiple of 64, <= LDS_VLOW)
     int anch[LDS_MAX_FAC];         // twiddle tables of the stage (radix 8 / 16): 1 = W^j only,
                                    // 2 = W^j, W^{4j}, 3 = W^{qj} for q = 1..4 (and 8, 12)
     int ntw;                       // entries of that table (tables x strides > 1)
@@ -114,6 +115,11 @@ __device__ __forceinline__ void twiddle_powers(cpx (&w)[16], const cpx* tw1, int
                                                int T) {
     w[1] = tw1[j];
     if constexpr (R >= 8) {
+        if (T == 4) {                          // every power from its own table
+#pragma unroll
+            for (int q = 2; q < R; ++q) w[q] = tw1[(q - 1) * stride + j];
+            return;
+        }
         if (T >= 2) {
             if (T == 3) {
                 w[2] = tw1[stride + j];
@@ -298,8 +304,8 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                                             float* __restrict__ out, float2* __restrict__ spec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx* z = reinterpret_cast<cpx*>(smem);                         // [M]
-    cpx* vlow = z + g.M;                                           // [LDS_VLOW]
-    cpx* tw1 = vlow + LDS_VLOW;                                    // [ntw] W_L^j per stage
+    cpx* vlow = z + g.M;                                           // [g.vlow]
+    cpx* tw1 = vlow + g.vlow;                                      // [ntw] W_L^j per stage
     float* scratch = reinterpret_cast<float*>(tw1 + g.ntw);        // [BT / 64]
     OfxCand* cscratch = reinterpret_cast<OfxCand*>(scratch + 32);  // [BT / 64]
     const int tid = threadIdx.x;
@@ -447,8 +453,8 @@ __global__ __launch_bounds__(BT) void k_lds(OfxPlanDev pd, LdsGeom g, const LdsS
                     vpc = (u + sv) * mk(0.5f, 0.5f);
                 }
                 const int kp = (k == 0) ? M : p;
-                if (k < LDS_VLOW) vlow[k] = vk;
-                if (kp < LDS_VLOW && kp != k) vlow[kp] = mk(vpc.x, -vpc.y);
+                if (k < g.vlow) vlow[k] = vk;
+                if (kp < g.vlow && kp != k) vlow[kp] = mk(vpc.x, -vpc.y);
                 if (sdp) {
                     acc = fmaf(cur.gk, vk.x * vk.x + vk.y * vk.y, acc);
                     acc = fmaf(cur.gp, vpc.x * vpc.x + vpc.y * vpc.y, acc);
@@ -584,9 +590,13 @@ bool factorize(int M, std::vector<int>* fac) {
 }
 
 // tables of one stage: exponents q of the tabulated W_L^{q j}
-int anchor_list(int r, int T, int (&e)[6]) {
+int anchor_list(int r, int T, int (&e)[16]) {
     e[0] = 1;
     if (r < 8 || T <= 1) return 1;
+    if (T == 4) {
+        for (int q = 1; q < r; ++q) e[q - 1] = q;
+        return r - 1;
+    }
     if (T == 2) { e[1] = 4; return 2; }
     e[1] = 2; e[2] = 3; e[3] = 4;
     if (r == 8) return 4;
@@ -597,22 +607,32 @@ int anchor_list(int r, int T, int (&e)[6]) {
 int stage_twiddle_count(int M, const std::vector<int>& fac, int T = 1) {
     int L = M, n = 0;
     for (int r : fac) {
-        int e[6];
+        int e[16];
         if (L / r > 1) n += anchor_list(r, T, e) * (L / r);
         L /= r;
     }
     return n;
 }
 
-// How many twiddle tables the radix-8 / 16 stages of a length-M transform get: the most
-// (3, then 2) that neither exceeds the LDS budget nor lowers the number of workgroups a CU
-// holds (other_bytes = everything else the kernel keeps in LDS besides data and twiddles).
+// How many twiddle tables the radix-8 / 16 stages of a length-M transform get: the highest
+// level (3, then 2) that fits the LDS budget and still leaves three workgroups per CU (or as
+// many as the single-table layout had, if fewer).  Level 3 is also the fastest where it fits
+// (9 instead of 14 products per radix-16 butterfly: 4096 samples 38.5 -> 49.8 M traces/s against
+// level 2) and brings the error at 4096 samples to that of the rocFFT path (chi2 max-rel
+// 7.7e-6, no time-bin flip in 8192 events; level 1: 2.8e-5, level 2: 1.4e-5).
+// other_bytes = everything else the kernel keeps in LDS besides data and twiddles.
 int choose_anchor_level(int M, const std::vector<int>& fac, size_t other_bytes) {
     const size_t base = other_bytes + (size_t)M * 8;
     const size_t b1 = base + (size_t)stage_twiddle_count(M, fac, 1) * 8;
+    if (const char* dg = getenv("OFX_DIAG_LDS_T")) {      // diagnostic: force the table level
+        const int T = atoi(dg);
+        if (T >= 1 && T <= 4 && base + (size_t)stage_twiddle_count(M, fac, T) * 8 <= LDS_BUDGET)
+            return T;
+    }
+    const size_t want = std::min<size_t>(LDS_BUDGET / b1, 3);
     for (int T = 3; T >= 2; --T) {
         const size_t bt = base + (size_t)stage_twiddle_count(M, fac, T) * 8;
-        if (bt <= LDS_BUDGET && LDS_BUDGET / bt == LDS_BUDGET / b1) return T;
+        if (bt <= LDS_BUDGET && LDS_BUDGET / bt >= want) return T;
     }
     return 1;
 }
@@ -622,6 +642,7 @@ void lds_layout(int M, const std::vector<int>& fac, int T, LdsGeom* g, std::vect
     memset(g, 0, sizeof(*g));
     g->M = M;
     g->N = 2 * M;
+    g->vlow = LDS_VLOW;
     g->nfac = (int)fac.size();
     int L = M;
     for (int i = 0; i < g->nfac; ++i) {
@@ -629,7 +650,7 @@ void lds_layout(int M, const std::vector<int>& fac, int T, LdsGeom* g, std::vect
         const unsigned stride = (unsigned)(L / fac[i]);
         g->magic[i] = (unsigned)((1ull << 32) / stride) + 1u;     // unused when stride == 1
         g->toff[i] = g->ntw;
-        int e[6];
+        int e[16];
         const int nt = anchor_list(fac[i], T, e);
         g->anch[i] = (fac[i] >= 8) ? T : 1;
         if (stride > 1) g->ntw += nt * (int)stride;
@@ -640,7 +661,7 @@ void lds_layout(int M, const std::vector<int>& fac, int T, LdsGeom* g, std::vect
     L = M;
     for (int i = 0; i < g->nfac; ++i) {
         const int stride = L / g->fac[i];
-        int e[6];
+        int e[16];
         const int nt = anchor_list(g->fac[i], T, e);
         if (stride > 1)
             for (int a = 0; a < nt; ++a)
@@ -764,15 +785,33 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     }
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
+    // low bins of V the plan reads back (lowchi2 cut-offs, psd_amp bands): the LDS set aside
+    // for them follows the plan, and what it leaves decides how many twiddle tables the
+    // radix-8 / 16 stages get (choose_anchor_level)
+    int vneed = 0;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s)
+        if (p->slot[s].set)
+            for (const OfxSearchDev& q : p->slot[s].searches) vneed = std::max(vneed, q.nlow);
+    for (const auto& bd : p->bands) vneed = std::max(vneed, bd.k_hi);
+    const int vlow_cap = std::min(LDS_VLOW, std::max(64, (vneed + 63) / 64 * 64));
+    const size_t other_bytes = (size_t)vlow_cap * 8 + 32 * 4 + 32 * sizeof(OfxCand);
+    const int T = choose_anchor_level(M, fac, other_bytes);
     LdsGeom g;
     std::vector<float2> t1;
-    lds_layout(M, fac, choose_anchor_level(M, fac, LDS_OTHER_BYTES), &g,
-               p->d_lds_tw ? nullptr : &t1);
+    const bool rebuild = !p->d_lds_tw || p->lds_tw_level != T;
+    lds_layout(M, fac, T, &g, rebuild ? &t1 : nullptr);
+    g.vlow = vlow_cap;
     const double c0 = -6.283185307179586476925286766559 / (double)N;
-    if (!p->d_lds_tw) {
+    if (rebuild) {
+        if (p->d_lds_tw) {
+            OFX_HIP(hipStreamSynchronize(st));     // an earlier launch may still read the tables
+            (void)hipFree(p->d_lds_tw);
+            p->d_lds_tw = nullptr;
+        }
         OFX_HIP(hipMalloc(&p->d_lds_tw, sizeof(float2) * t1.size()));
         OFX_HIP(hipMemcpy(p->d_lds_tw, t1.data(), sizeof(float2) * t1.size(),
                           hipMemcpyHostToDevice));
+        p->lds_tw_level = T;
     }
     std::vector<LdsSlot> args;
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
@@ -853,7 +892,7 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
     }
     // about one widest butterfly per thread and stage
     const int bf = M / fac[0];
-    const size_t lds = lds_bytes_for(M, fac);
+    const size_t lds = (size_t)M * 8 + other_bytes + (size_t)g.ntw * 8;
     // the register prefetch of the next trace pays when only one workgroup fits a CU
     // (nothing else hides the HBM latency); with many small workgroups it only costs occupancy
     const bool pf = lds > 80 * 1024;
