@@ -254,7 +254,8 @@ def run_fused(cases, seed, verbose=True):
         tdw = []
         for _ in range(int(rng.integers(0, 4))):
             lo = int(rng.integers(0, n - 2)); tdw.append((lo, int(rng.integers(lo + 1, n))))
-        tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)}'
+        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, 120000.0]))     # beyond 512 bins: the stash
+        tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)} fcut={fcut_c}'
         outs = {}
         try:
             for eng in ('fused', 'rocfft'):
@@ -262,7 +263,7 @@ def run_fused(cases, seed, verbose=True):
                 ids = []
                 for s, ft in enumerate(fts):
                     plan.set_filter(s, ft)
-                    ids.append([plan.add_search(s, k, lo, hi, outside, 10000.0, interp) for (k, lo, hi, outside, interp) in searches[s]])
+                    ids.append([plan.add_search(s, k, lo, hi, outside, fcut_c, interp) for (k, lo, hi, outside, interp) in searches[s]])
                 wids = [plan.add_tdwindow(lo, hi) for lo, hi in tdw]
                 if n_total > 1 or nterm > 1 or weights[0] != 1.0:
                     plan.set_channels(n_total, chans, weights)
@@ -291,10 +292,10 @@ def run_fused(cases, seed, verbose=True):
                     if not np.all(da <= lim):
                         w_ = int(np.argmax(da / lim))
                         e_ = int(np.nonzero(ok)[0][same][w_])
-                        r_ = orc.process_events(filts[s], comb[e_:e_ + 1], 'nodelay' if k == 'nodelay' else 'constrained', 10000.0,
+                        r_ = orc.process_events(filts[s], comb[e_:e_ + 1], 'nodelay' if k == 'nodelay' else 'constrained', fcut_c,
                                                 interpolate=interp, **({} if k == 'nodelay' else dict(
                                                     window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
-                        r0_ = orc.process_events(filts[s], comb[e_:e_ + 1], 'nodelay' if k == 'nodelay' else 'constrained', 10000.0,
+                        r0_ = orc.process_events(filts[s], comb[e_:e_ + 1], 'nodelay' if k == 'nodelay' else 'constrained', fcut_c,
                                                  interpolate=False, **({} if k == 'nodelay' else dict(
                                                      window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
                         print(f'   oracle amp {r_["amp"][0]:.4e} t0 {r_["t0"][0]:.6e} idx {r_["index"][0]} | no-interp amp {r0_["amp"][0]:.4e} | '
@@ -305,7 +306,7 @@ def run_fused(cases, seed, verbose=True):
                     assert np.allclose(a[ok][:, o + 2], b[ok][:, o + 2], rtol=2e-4), tag + f' chi2 s{s} q{q}'
                     sel = np.nonzero(ok)[0][:4]
                     mode = 'nodelay' if k == 'nodelay' else 'constrained'
-                    r = orc.process_events(filts[s], comb[sel], mode, 10000.0, interpolate=interp,
+                    r = orc.process_events(filts[s], comb[sel], mode, fcut_c, interpolate=interp,
                                            **({} if k == 'nodelay' else dict(window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
                     if np.all(r['index'] >= 0):
                         # the sub-sample offset of a noise peak is a ratio of amplitude differences far
