@@ -605,3 +605,30 @@ def test_run_sharded_streaming_equals_resident():
     ref = orc.process_events(orc.OFFilter(tmpl, psd, FS, pre), shard[:16].cpu().numpy().astype(np.float64),
                              "unconstrained")
     check_search(want[:16].cpu().numpy().astype(np.float64), 0, ref, "", ft.ampres, FS, "sharded")
+
+
+def test_rejected_filter_table_leaves_the_plan_as_it_was():
+    """ofx_plan_set_filter validates before it frees: a NaN table for slot 1 of a three-slot FUSED
+    plan is refused and the plan keeps producing the rows it produced before (no stale device
+    slot table, no freed pointers)."""
+    import copy
+    from detprocess_amd import _lib, build_filter
+    n = 32768
+    plan, ft, filt, tmpl, psd = _mk(n, engine="fused")
+    ft2 = build_filter(synth.make_template(n, n // 2, FS, "glitch"), psd, FS, n // 2)
+    plan.set_filter(1, ft2)
+    plan.set_filter(2, ft)
+    ids = [plan.add_search(s, "delay") for s in range(3)]
+    x, _, _ = synth.make_traces(9, tmpl, psd, FS, ft.ampres, seed=4)
+    x32 = x.astype(np.float32)
+    before = _run(plan, x32)
+    bad = copy.copy(ft2)
+    bad.wf = ft2.wf.copy()
+    bad.wf[100] = np.nan
+    with pytest.raises(ValueError, match="non-finite"):        # OFX_ERR_ARG -> ValueError
+        plan.set_filter(1, bad)
+    assert [plan.search_offset(s, ids[s]) for s in range(3)] == [0, 8, 16]
+    assert np.array_equal(_run(plan, x32), before)
+    plan.set_filter(1, ft)              # and a good table afterwards takes effect
+    after = _run(plan, x32)
+    assert np.array_equal(after[:, 8:16], before[:, 0:8]) and np.array_equal(after[:, 0:8], before[:, 0:8])

@@ -718,3 +718,37 @@ def test_duplicate_yaml_keys_are_refused():
     bad2 = "A:\n    baseline:\n        run: True\n        run: False\n"
     with pytest.raises(ValueError, match='Duplicate key "run"'):
         YamlConfig(bad2, ["A"], sample_rate=FS)
+
+
+@pytest.mark.gpu
+def test_combined_channel_needs_its_own_filter_entry_and_single_channels_ignore_weights():
+    """processing_data.py:295, 345: templates and CSDs are looked up with the YAML channel
+    expression itself ('A+B' needs an 'A+B' entry; no silent use of A's filter);
+    processing_data.py:1033-1047: weights only act where there is a '+' / '-'."""
+    from detprocess_amd import FeatureProcessing
+    n, pre, B = 32768, 16384, 4
+    fd = FilterData()
+    f = np.fft.fftfreq(n, d=1 / FS)
+    J = synth.make_psd(n, FS)
+    for ch in ("A", "B"):
+        fd.set_template(ch, synth.make_template(n, pre, FS), sample_rate=FS,
+                        pretrigger_length_samples=pre, tag="default")
+        fd.set_psd(ch, J, f, sample_rate=FS, tag="default")
+    ev, _, _ = synth.make_traces(2 * B, synth.make_template(n, pre, FS), J, FS, 1e-9, seed=3)
+    ev = ev.reshape(B, 2, n).astype(np.float32)
+    summed = ("A+B:\n    weight_A: 0.9\n    weight_B: 1.1\n    of1x1_nodelay:\n        run: True\n"
+              "        template_tag: default\n")
+    with pytest.raises(ValueError, match='Channel "A\\+B" not available'):
+        FeatureProcessing(summed, fd, ["A", "B"], FS).process(ev)
+    single = ("A:\n    weight_A: 3.0\n    of1x1_nodelay:\n        run: True\n        template_tag: default\n"
+              "    maximum:\n        run: True\n")
+    plain = "A:\n    of1x1_nodelay:\n        run: True\n        template_tag: default\n    maximum:\n        run: True\n"
+    a = FeatureProcessing(single, fd, ["A", "B"], FS).process(ev)
+    b = FeatureProcessing(plain, fd, ["A", "B"], FS).process(ev)
+    assert np.array_equal(a["amp_of1x1_nodelay_A"], b["amp_of1x1_nodelay_A"])
+    assert np.array_equal(a["maximum_A"], ev[:, 0, :-1].max(axis=1).astype(np.float64))
+    # a list / NumPy valid mask next to CUDA events (engine.py: torch.as_tensor on the mask)
+    import torch
+    fp = FeatureProcessing(plain, fd, ["A", "B"], FS)
+    d1 = fp.process(torch.as_tensor(ev, device="cuda:0"), valid=[1, 0, 1, 1])
+    assert (d1.iloc[1] == -999999.0).all() and np.array_equal(d1["maximum_A"][[0, 2, 3]], b["maximum_A"][[0, 2, 3]])
