@@ -611,14 +611,33 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     };
 
     // Trace load into the register file (virtual thread vt reads z[512 n1 + vt]).
+    // FEAT & 4 (channel algebra): the request only carries the first term, unscaled, so that it
+    // stays a plain asynchronous prefetch; the weight and the other terms are applied by
+    // combine_terms when the trace is taken up (with the FMA next to the loads the "prefetch" of a
+    // 4-channel plan waited for every load in turn: 72 k cycles per trace in the timeline of
+    // BASELINE configs[3]).  The arithmetic is unchanged: w0 s0, then fma(w_c, s_c, .) in order.
     auto load_trace = [&](long long bb) __attribute__((always_inline)) {
         int tl = tid;
         asm volatile("" : "+v"(tl));
         const float* e = traces + (size_t)bb * ev_stride;
-        if constexpr (FEAT & 4) {
+        const __amdgpu_buffer_rsrc_t rz =
+            make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * FN : 0), FN * 4);
 #pragma unroll
-            for (int j = 0; j < NV; ++j) d[j] = mk(0.f, 0.f);
-            for (int c = 0; c < pd.n_terms; ++c) {
+        for (int h = 0; h < VT; ++h)
+#pragma unroll
+            for (int n1 = 0; n1 < 32; ++n1)
+                d[32 * h + n1] = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
+    };
+    auto combine_terms = [&](long long bb) __attribute__((always_inline)) {
+        if constexpr (FEAT & 4) {
+            if (pd.n_terms == 1 && pd.weight[0] == 1.0f) return;         // uniform: a plain select
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+            const float* e = traces + (size_t)bb * ev_stride;
+            const float w0 = pd.weight[0];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) d[j] = d[j] * mk(w0, w0);
+            for (int c = 1; c < pd.n_terms; ++c) {
                 const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + (size_t)pd.chan[c] * FN, FN * 4);
                 const float wgt = pd.weight[c];
 #pragma unroll
@@ -629,13 +648,6 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                         d[32 * h + n1] = pfma(mk(wgt, wgt), s, d[32 * h + n1]);
                     }
             }
-        } else {
-            const __amdgpu_buffer_rsrc_t rz = make_rsrc(e, FN * 4);
-#pragma unroll
-            for (int h = 0; h < VT; ++h)
-#pragma unroll
-                for (int n1 = 0; n1 < 32; ++n1)
-                    d[32 * h + n1] = buf_ld2(rz, (tl + FT * h) * 8, n1 * 4096);
         }
     };
 
@@ -670,7 +682,9 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     {
         const size_t off = (((size_t)wg * OFX_STAMP_TRACES) * NWAVE +
                             (size_t)__builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & (NWAVE - 1))) * 16;
-        const unsigned long long a = reinterpret_cast<unsigned long long>(xwide) + off * 8;
+        // (the stamps live behind the stash area of the WIDE variants in the same buffer)
+        const unsigned long long a = reinterpret_cast<unsigned long long>(
+            xwide + (size_t)gridDim.x * NHALF * (NS_MAX - NLOW_MAX)) + off * 8;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
         const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
         stamp_base = reinterpret_cast<unsigned long long*>(((unsigned long long)hi << 32) | lo);
@@ -713,6 +727,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
 
         STAMP(0);                                // loop overhead / previous tail remainder
         if (!have) load_trace(b);               // cold start / after an invalid event
+        combine_terms(b);
 
         // ------------------------------------------------ time-domain windows
         // Sample index of d[32 h + n1].{x,y} is 1024 n1 + 2 vt + {0,1}: a window [lo, hi)
@@ -1456,10 +1471,11 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
 #ifdef OFX_STAMPS
     const size_t stamp_bytes =
         (size_t)grid * NHALF * OFX_STAMP_TRACES * NWAVE * 16 * sizeof(unsigned long long);
+    const size_t stash_bytes = (size_t)grid * NHALF * (NS_MAX - NLOW_MAX) * sizeof(float2);
     if (p->d_fused_xwide) (void)hipFree(p->d_fused_xwide);
     p->d_fused_xwide = nullptr;
-    OFX_HIP(hipMalloc(&p->d_fused_xwide, stamp_bytes));
-    OFX_HIP(hipMemset(p->d_fused_xwide, 0, stamp_bytes));
+    OFX_HIP(hipMalloc(&p->d_fused_xwide, stash_bytes + stamp_bytes));
+    OFX_HIP(hipMemset(p->d_fused_xwide, 0, stash_bytes + stamp_bytes));
 #endif
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
@@ -1475,7 +1491,8 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
     if (const char* f = getenv("OFX_STAMP_FILE")) {
         OFX_HIP(hipStreamSynchronize(st));
         std::vector<unsigned long long> h(stamp_bytes / 8);
-        OFX_HIP(hipMemcpy(h.data(), p->d_fused_xwide, stamp_bytes, hipMemcpyDeviceToHost));
+        OFX_HIP(hipMemcpy(h.data(), reinterpret_cast<char*>(p->d_fused_xwide) + stash_bytes,
+                          stamp_bytes, hipMemcpyDeviceToHost));
         if (FILE* fp = fopen(f, "wb")) {
             fwrite(h.data(), 8, h.size(), fp);
             fclose(fp);

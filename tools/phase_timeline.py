@@ -14,10 +14,28 @@ NT = 40
 NW = 4
 
 
-def run(n, wgpc, path):
+def run(n, wgpc, path, config3=False):
     env = dict(os.environ, OFX_STAMP_FILE=path)
     if wgpc == 1:
         env['OFX_DIAG_WGPC'] = '1'
+    if config3:
+        code = f'''
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from detprocess_amd import FeatureProcessing, build_filter, synth, SynthSource
+N=32768; fs=1.25e6; pre=N//2
+tmpl=synth.make_template(N,pre,fs); psd=synth.make_psd(N,fs); ft=build_filter(tmpl,psd,fs,pre)
+gen=SynthSource(N,tmpl,psd,fs,3*ft.ampres,300*ft.ampres,0.5,2000,seed=1)
+B={n}//4
+x=torch.empty((B,4,N),dtype=torch.float32,device='cuda:0'); gen.fill(0,B*4,x.reshape(B*4,N))
+fp=FeatureProcessing(bench.yaml_config3(), bench.filter_data3(pre), bench.CHANNELS3, fs)
+for _ in range(2): fp.process_device(x)
+torch.cuda.synchronize()
+'''
+        subprocess.run([sys.executable, '-c', code], env=env, check=True)
+        a = np.fromfile(path, dtype=np.uint64).reshape(-1, NT, NW, 16)
+        return a[:, :, 0, :]
     code = f'''
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
@@ -96,6 +114,16 @@ def overlap(a):
 
 
 if __name__ == '__main__':
+    if '--config3' in sys.argv:
+        # BASELINE configs[3] (three slots, nine searches, windows, bands): the stamps of a trace
+        # cover its last slot pass only (markers 5..12 are re-stamped per slot), the total is exact
+        sys.argv.remove('--config3')
+        a3 = run(int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 2, '/tmp/stamps3.bin', config3=True)
+        rep = {'cycles_per_phase_config3_last_slot': summarise(a3)}
+        json.dump(rep, open(sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline_c3.json', 'w'), indent=1)
+        for k, v in rep['cycles_per_phase_config3_last_slot'].items():
+            print(f'{k:8s} {v:9.0f}')
+        sys.exit(0)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     dest = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline.json'
     a2 = run(n, 2, '/tmp/stamps2.bin')
