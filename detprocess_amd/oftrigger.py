@@ -61,6 +61,29 @@ def _lowpass_50khz_window(raw, fs, start, stop, pad=1024):
     return filtfilt(b, a, seg, padtype="even")[start - a0: stop - a0]
 
 
+def pulse_table(template, phi_td, iw_eff, w_matrix):
+    """G[a][b][z]: the delta-chi2 trace of a best-fit pulse with amplitudes A is
+    sum_ab A_a A_b G_ab[z] -- oftrigger.py:793-809 with the amplitudes taken out of the
+    convolutions.  template [C, M, T], phi_td [C, M, T] (as the reference stores them), iw_eff the
+    matrix that turns the summed convolutions into amplitudes, w_matrix the weight matrix.  The
+    filter of amplitude theta is indexed as the reference indexes it in this loop
+    (``self._phi_td[theta, :]``, oftrigger.py:800; update_trace uses ``[:, theta, :]``, :658):
+    identical for one channel x one amplitude, and the reference's own expression only runs when
+    the two counts agree (or one is 1); other shapes use the update_trace convention."""
+    from scipy.signal import oaconvolve
+    C_, M, T = template.shape
+    lit = (C_ == M) or C_ == 1 or M == 1
+    f = np.zeros((M, M, T))                            # f[a][i][z] = (iw U_a)[i][z]
+    for a in range(M):
+        U = np.zeros((M, T))
+        for theta in range(M):
+            kern = phi_td[theta] if lit else phi_td[:, theta, :]
+            kern = np.broadcast_to(kern, (C_, T)) if kern.shape[0] != C_ else kern
+            U[theta] = np.sum(oaconvolve(template[:, a, :], kern, mode="same", axes=-1), axis=0)
+        f[a] = iw_eff @ U
+    return np.ascontiguousarray(np.einsum("aiz,ij,bjz->abz", f, w_matrix, f))
+
+
 def _chi2_threshold(thresh, m_amplitudes=1):
     """sigma -> chi2 threshold, oftrigger.py:962-975."""
     from scipy import special, stats
@@ -288,30 +311,11 @@ class OptimumFilterTrigger:
 
     # ------------------------------------------------------------ residual pass
     def _pulse_table(self):
-        """G[a][b][z]: the delta-chi2 trace of a best-fit pulse with amplitudes A is
-        sum_ab A_a A_b G_ab[z] -- oftrigger.py:793-809 with the amplitudes taken out of the
-        convolutions.  The filter of amplitude theta is indexed as the reference indexes it in
-        this loop (``self._phi_td[theta, :]``, oftrigger.py:800; update_trace uses
-        ``[:, theta, :]``, :658): identical for one channel x one amplitude, and the
-        reference's own expression only runs when the two counts agree (or one is 1); other
-        shapes use the update_trace convention."""
-        from scipy.signal import oaconvolve
-        C_, M, T = self._n_channels, self._m_amplitudes, self._t_times
-        if C_ == 1 and M == 1:
+        if self._n_channels == 1 and self._m_amplitudes == 1:
             iw_eff = np.array([[1.0 / (float(self._w_matrix[0, 0]) * self._fs)]])
         else:
             iw_eff = self._iw_matrix / self._fs
-        lit = (C_ == M) or C_ == 1 or M == 1
-        f = np.zeros((M, M, T))                            # f[a][i][z] = (iw U_a)[i][z]
-        for a in range(M):
-            U = np.zeros((M, T))
-            for theta in range(M):
-                kern = self._phi_td[theta] if lit else self._phi_td[:, theta, :]
-                kern = np.broadcast_to(kern, (C_, T)) if kern.shape[0] != C_ else kern
-                U[theta] = np.sum(oaconvolve(self._template[:, a, :], kern, mode="same", axes=-1),
-                                  axis=0)
-            f[a] = iw_eff @ U
-        return np.ascontiguousarray(np.einsum("aiz,ij,bjz->abz", f, self._w_matrix, f))
+        return pulse_table(self._template, self._phi_td, iw_eff, self._w_matrix)
 
     def _saturated(self, trigger_index, positive_pulses, sat):
         """oftrigger.py:772-786: a first-pass trigger is vetoed when the 50 kHz low-passed raw

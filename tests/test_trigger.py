@@ -494,3 +494,36 @@ def test_gpu_residual_pass_two_channels_two_amplitudes():
     assert np.max(np.abs(out[3].astype(np.float64) - residual)) <= 2e-4 * dmax
     c2 = {int(i) for i, d in zip(second["trigger_index"], second["trigger_delta_chi2"]) if d > 2 * thr}
     assert c2 <= set(out[2]["AB"]["trigger_index"])
+
+
+@pytest.mark.parametrize("shape", ["1x1", "2x2"])
+def test_pulse_table_reproduces_the_per_trigger_construction(shape):
+    """detprocess_amd.oftrigger.pulse_table (host precompute of the residual pass): for random
+    amplitudes sum_ab A_a A_b G_ab[z] equals the delta-chi2 pulse the reference builds per trigger
+    (oftrigger.py:793-809), as restated by the oracle's find_triggers_residual."""
+    from detprocess_amd.oftrigger import pulse_table
+    from scipy.signal import oaconvolve
+    n, pre = 1024, 512
+    rng = np.random.default_rng(2)
+    if shape == "1x1":
+        tmpl = synth.make_template(n, pre, FS)
+        t = ot.OFTrigger(FS, tmpl, synth.make_psd(n, FS), pre)
+        G = pulse_table(tmpl.reshape(1, 1, n), t.phi_td.reshape(1, 1, n),
+                        np.array([[1.0 / t.vscale]]), np.array([[t.w]]))
+        for amp in (3e-8, -1.2e-7):
+            v = oaconvolve(tmpl * amp, t.phi_td, mode="same") / t.vscale
+            assert np.allclose(amp * amp * G[0, 0], v * t.w * v, rtol=1e-10, atol=1e-12 * np.max(v * t.w * v))
+        return
+    from test_ofnxm import make_csd, make_templates
+    tm = make_templates(n, pre, 2, 2)
+    t = ot.OFTriggerNxM(FS, tm, make_csd(n, 2), pre)
+    G = pulse_table(tm, t.phi_td, t.iw_matrix / FS, t.w_matrix)
+    for _ in range(3):
+        amps = rng.normal(size=2) * t.resolution * 30
+        trig_trace = sum(tm[:, m, :] * amps[m] for m in range(2))
+        v_td = np.stack([np.sum(oaconvolve(trig_trace, t.phi_td[theta, :], mode="same", axes=-1), axis=0)
+                         for theta in range(2)])
+        filt = np.einsum("ij,jz->iz", t.iw_matrix / FS, v_td)
+        want = np.einsum("iz,ij,jz->z", filt, t.w_matrix, filt)
+        got = np.einsum("a,b,abz->z", amps, amps, G)
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-12 * np.max(want))
