@@ -18,6 +18,25 @@ def run(n, wgpc, path, config3=False):
     env = dict(os.environ, OFX_STAMP_FILE=path)
     if wgpc == 1:
         env['OFX_DIAG_WGPC'] = '1'
+    if config3 == 2:
+        code = f'''
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from detprocess_amd import OFPlan, build_filter, synth, SynthSource, search_range, utils
+N=32768; fs=1.25e6; pre=N//2
+tmpl=synth.make_template(N,pre,fs); psd=synth.make_psd(N,fs); ft=build_filter(tmpl,psd,fs,pre)
+gen=SynthSource(N,tmpl,psd,fs,3*ft.ampres,300*ft.ampres,0.5,2000,seed=1)
+x=torch.empty(({n},N),dtype=torch.float32,device='cuda:0'); gen.fill(0,{n},x)
+plan=OFPlan(N,pre,fs,max_batch=8192,engine='fused'); plan.set_filter(0,ft)
+lo,hi=search_range(N,pre,fs,-400,400); plan.add_search(0,'delay',lo,hi)
+plan.add_tdwindow(*utils.get_window_indices(nb_samples=N,nb_pretrigger_samples=pre,fs=fs,window_min_from_trig_usec=-10,window_max_from_trig_usec=500))
+plan.add_tdwindow(*utils.get_window_indices(nb_samples=N,nb_pretrigger_samples=pre,fs=fs,window_min_from_trig_usec=-500,window_max_from_trig_usec=500))
+for _ in range(3): plan.process(x)
+torch.cuda.synchronize()
+'''
+        subprocess.run([sys.executable, '-c', code], env=env, check=True)
+        a = np.fromfile(path, dtype=np.uint64).reshape(-1, NT, NW, 16)
+        return a[:, :, 0, :]
     if config3:
         code = f'''
 import sys, numpy as np, torch
@@ -114,6 +133,15 @@ def overlap(a):
 
 
 if __name__ == '__main__':
+    if '--config2' in sys.argv:
+        sys.argv.remove('--config2')
+        a2 = run(int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 2, '/tmp/stamps2c.bin', config3=2)
+        rep = {'cycles_per_phase_config2': summarise(a2), 'overlap_2wg': overlap(a2)}
+        json.dump(rep, open(sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline_c2.json', 'w'), indent=1)
+        for k, v in rep['cycles_per_phase_config2'].items():
+            print(f'{k:8s} {v:9.0f}')
+        print(rep['overlap_2wg'])
+        sys.exit(0)
     if '--config3' in sys.argv:
         # BASELINE configs[3] (three slots, nine searches, windows, bands): the stamps of a trace
         # cover its last slot pass only (markers 5..12 are re-stamped per slot), the total is exact
