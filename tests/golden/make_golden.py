@@ -88,8 +88,53 @@ def make_trigger(fname="golden_trigger_n4096.npz"):
     print(fname, "written")
 
 
+def make_trigger_residual(fname="golden_trigger_residual_n4096.npz"):
+    """Dynamic pile-up window and residual pass (oracle/oftrigger.py; oftrigger.py:78-143,
+    752-845): a stream with small pulses on the tails of large ones; triggers of the dynamic
+    window w(d) = w0 + w1 min(1, d / dref), first / second pass and combined indices of the
+    residual pass with a static window, the residual delta-chi2 trace at probe points."""
+    from oracle import oftrigger as ot
+    n, pre, L = 4096, 2048, 300000
+    rng = np.random.default_rng(77)
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    t = ot.OFTrigger(FS, tmpl, psd, pre)
+    x = synth.coloured_noise(rng, L // n + 2, psd, FS).reshape(-1)[:L]
+    onsets = np.sort(rng.integers(2 * n, L - 3 * n, 10))
+    for p in onsets:
+        x[p:p + n] += t.resolution * rng.uniform(20, 80) * tmpl
+    extra = []
+    for p in onsets[::2]:
+        q = int(p + rng.integers(n // 8, n // 3))
+        x[q:q + n] += t.resolution * rng.uniform(12, 25) * tmpl
+        extra.append(q)
+    x32 = x.astype(np.float32)
+    x64 = x32.astype(np.float64)
+    t.update_trace(x64)
+    dref = float(np.max(t.delta_chi2))
+    w0, w1 = 50.0, 0.4 * n
+    fn = lambda d: w0 + w1 * min(1.0, d / dref)
+    out = {"template": tmpl, "psd": psd, "fs": FS, "pre": pre, "stream": x32, "onsets": onsets,
+           "extra": np.asarray(extra), "dyn_w0": w0, "dyn_w1": w1, "dyn_dref": dref,
+           "dchi2_max": dref, "filtered_max": np.max(np.abs(t.filtered))}
+    r = t.find_triggers(6.0, dynamic_function=fn)
+    out["chi2_threshold"] = r["chi2_threshold"]
+    for k in ("trigger_index", "trigger_delta_chi2", "trigger_amplitude"):
+        out[f"dyn_{k}"] = r[k]
+    first, second, residual, combined = t.find_triggers_residual(6.0, x64, pileup_window_samples=n // 2)
+    for nm, rr in (("first", first), ("second", second)):
+        for k in ("trigger_index", "trigger_delta_chi2", "trigger_amplitude"):
+            out[f"res_{nm}_{k}"] = rr[k]
+    out["res_combined_index"] = combined
+    out["res_window"] = n // 2
+    out["residual_probe"] = residual[::499]
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, "written")
+
+
 if __name__ == "__main__":
     make_trigger()
+    make_trigger_residual()
     make(4096, 32, seed=41, fname="golden_n4096.npz")
     make(4096, 8, seed=42, pre=1000, fname="golden_n4096_pre1000.npz")
     make(32768, 6, seed=43, fname="golden_n32768.npz")

@@ -527,3 +527,53 @@ def test_pulse_table_reproduces_the_per_trigger_construction(shape):
         want = np.einsum("iz,ij,jz->z", filt, t.w_matrix, filt)
         got = np.einsum("a,b,abz->z", amps, amps, G)
         assert np.allclose(got, want, rtol=1e-9, atol=1e-12 * np.max(want))
+
+
+def _load_residual_golden():
+    from util import load_golden
+    return load_golden("golden_trigger_residual_n4096.npz")
+
+
+def test_oracle_reproduces_residual_golden():
+    g = _load_residual_golden()
+    t = ot.OFTrigger(float(g["fs"]), g["template"], g["psd"], int(g["pre"]))
+    x64 = g["stream"].astype(np.float64)
+    t.update_trace(x64)
+    fn = lambda d: float(g["dyn_w0"]) + float(g["dyn_w1"]) * min(1.0, d / float(g["dyn_dref"]))
+    r = t.find_triggers(6.0, dynamic_function=fn)
+    assert np.array_equal(r["trigger_index"], g["dyn_trigger_index"])
+    first, second, residual, combined = t.find_triggers_residual(
+        6.0, x64, pileup_window_samples=int(g["res_window"]))
+    assert np.array_equal(first["trigger_index"], g["res_first_trigger_index"])
+    assert np.array_equal(second["trigger_index"], g["res_second_trigger_index"])
+    assert np.array_equal(combined, g["res_combined_index"])
+    assert np.allclose(residual[::499], g["residual_probe"], rtol=1e-10, atol=1e-12 * float(g["dchi2_max"]))
+    # the fixture does what it is for: the second pass brings out pulses the first one merged
+    new = set(g["res_second_trigger_index"].tolist()) - set(g["res_first_trigger_index"].tolist())
+    pre = int(g["pre"])
+    assert sum(any(abs(q + pre + 1 - i) <= 3 for i in new) for q in g["extra"]) >= 3
+
+
+@pytest.mark.gpu
+def test_gpu_trigger_reproduces_residual_golden():
+    from detprocess_amd import OptimumFilterTrigger
+    g = _load_residual_golden()
+    fs, pre = float(g["fs"]), int(g["pre"])
+    trig = OptimumFilterTrigger("chanA", fs, g["template"], g["psd"], pre)
+    trig.update_trace(g["stream"])
+    thr, dmax = float(g["chi2_threshold"]), float(g["dchi2_max"])
+    fn = lambda d: float(g["dyn_w0"]) + float(g["dyn_w1"]) * min(1.0, d / float(g["dyn_dref"]))
+    trig.find_triggers(6.0, dynamic=True, dynamic_threshold_function=fn)
+    got = trig.get_trigger_data()["chanA"]["trigger_index"]
+    clear = [int(i) for i, d in zip(g["dyn_trigger_index"], g["dyn_trigger_delta_chi2"]) if d > 2 * thr]
+    assert set(clear) <= set(got) and abs(len(got) - len(g["dyn_trigger_index"])) <= 2
+    out = trig.find_triggers(6.0, pileup_window_samples=int(g["res_window"]), residual=True,
+                             return_trigger_data=True)
+    for key, o in (("first", out[0]), ("second", out[2])):
+        want = {int(i) for i, d in zip(g[f"res_{key}_trigger_index"], g[f"res_{key}_trigger_delta_chi2"])
+                if d > 2 * thr}
+        assert want <= set(o["chanA"]["trigger_index"]), key
+    assert np.max(np.abs(out[3][::499].astype(np.float64) - g["residual_probe"])) <= 1e-4 * dmax
+    comb = trig.get_trigger_data()["chanA"]["trigger_index"]
+    assert {int(i) for i in g["res_combined_index"]
+            if i in set(g["res_first_trigger_index"].tolist())} <= set(comb)
