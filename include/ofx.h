@@ -126,6 +126,11 @@ int ofx_plan_set_filter(ofx_plan* plan, int slot, const double* wf,
  * per-event qp.OF1x1(...).calc(...) arguments -- algorithms.py:336-338,
  * 414-418, 538-547.  [lo, hi) is the half-open range of ROLLED bin indices
  * searched (outside != 0: its complement); ignored for OFX_SEARCH_NODELAY.
+ * lowchi2_fcutoff: bins with |f_k| <= cutoff enter lowchi2.  Engine limits on that count
+ * (checked at ofx_process, OFX_ERR_UNSUPPORTED; an OFX_ENGINE_AUTO plan then runs the call on
+ * the ROCFFT engine): FUSED 4096 bins (156 kHz at 32768 samples / 1.25 MHz; the reference
+ * example's 50 kHz = 1311 bins, examples/processing/process_example.yaml:113), LDS 1024 bins,
+ * ROCFFT none.  The same limits hold for the upper bin of ofx_plan_add_band.
  * Returns the search id (>= 0) or a negative error.
  */
 int ofx_plan_add_search(ofx_plan* plan, int slot, int kind, int lo, int hi,
