@@ -270,6 +270,8 @@ def main():
     free, _ = torch.cuda.mem_get_info(dev)
     maxB = int((free - (8 << 30)) // (C * N_SAMPLES * 4 + 1024))
     B = min(B, maxB)
+    if streaming:                  # two event buffers of one chunk each must fit
+        args.chunk = max(1, min(args.chunk, B // 2))
     if world > 1:       # every rank holds the same number of events (weak scaling)
         tb = torch.tensor([B], dtype=torch.int64, device=dev)
         dist.all_reduce(tb, op=dist.ReduceOp.MIN)

@@ -92,6 +92,9 @@ def run_sharded(total_events, chunk, source, process, row_floats, event_shape, r
             buffers = [torch.empty((cmax,) + tuple(event_shape), dtype=dtype, device=dev)
                        for _ in range(nbuf)]
         nbuf = len(buffers)
+        if any(bf.shape[0] < cmax for bf in buffers):
+            raise ValueError(f"ERROR: event buffers hold {min(bf.shape[0] for bf in buffers)} "
+                             f"events, chunks have up to {cmax}")
         if cuda:
             compute = torch.cuda.current_stream(dev)
             producer = torch.cuda.Stream(dev) if nbuf > 1 else compute
