@@ -160,3 +160,36 @@ def test_nan_trace_gives_a_nan_row_not_a_finite_one():
             assert np.all(np.isfinite(out[[0, 2], o:o + 8])), engine
             assert out[0, o + 7] == pre
         plan.close()
+
+
+@pytest.mark.parametrize("n,pre", [(4096, 1500), (32768, 16384)])
+def test_trigger_known_answers_without_the_oracle(n, pre):
+    """Continuous-data trigger on noiseless pulses: the filtered trace equals the pulse amplitude
+    at the pulse (the estimator's defining property), delta chi2 = A^2 norm there, the trigger
+    sits one sample after onset + pretrigger (the in-tree 'same'-mode convolution,
+    oftrigger.py:649-662, with the shift of :1005), pulses closer than the static pile-up window
+    merge into the larger one, the edges are zeroed (:674-679)."""
+    from detprocess_amd import OptimumFilterTrigger
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    norm, _ = _norm_from_definitions(tmpl, psd)
+    L = 30 * n
+    x = np.zeros(L, dtype=np.float64)
+    pos = [3 * n, 9 * n, 9 * n + n // 5, 20 * n]
+    amps = [1e-7, 2e-7, 0.5e-7, 3e-7]
+    for p, a in zip(pos, amps):
+        x[p:p + n] += a * tmpl
+    trig = OptimumFilterTrigger("chanA", FS, tmpl, psd, pre)
+    assert trig.get_resolution()[0] == pytest.approx(1 / np.sqrt(norm), rel=1e-9)
+    trig.update_trace(x.astype(np.float32))
+    d = trig.get_filtered_delta_chi2()
+    assert np.all(d[:n] == 0) and np.all(d[L - n + 1:] == 0)
+    trig.find_triggers(5.0, pileup_window_samples=n // 2)
+    td = trig.get_trigger_data()["chanA"]
+    assert td["trigger_index"] == [pos[0] + pre + 1, pos[1] + pre + 1, pos[3] + pre + 1]
+    for i, a in zip(range(3), (amps[0], amps[1], amps[3])):
+        assert td["trigger_amplitude"][i] == pytest.approx(a, rel=3e-5)
+        assert td["trigger_delta_chi2"][i] == pytest.approx(a * a * norm, rel=1e-4)
+    assert td["trigger_time"][0] == pytest.approx((pos[0] + pre + 1) / FS, rel=1e-12)
+    trig.find_triggers(5.0, pileup_window_samples=0)
+    assert len(trig.get_trigger_data()["chanA"]["trigger_index"]) >= 4
