@@ -366,16 +366,16 @@ class OptimumFilterTrigger:
         _lib.check(self._lib.ofx_trigger_residual_subtract(
             self._h, keep.ctypes.data if len(keep) else None, len(keep), None),
             "ofx_trigger_residual_subtract")
-        self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
-                                dynamic_threshold_function)
-        new_triggers = list(self._trigger_data[name]["trigger_index"])
-        new_trigger_data = copy.deepcopy(self._trigger_data)
-        res = None
-        if return_trigger_data:
-            res = np.empty(self._n, dtype=np.float32)
-        _lib.check(self._lib.ofx_trigger_residual_restore(
-            self._h, res.ctypes.data if res is not None else None, _lib.MEM_HOST, None),
-            "ofx_trigger_residual_restore")
+        res = np.empty(self._n, dtype=np.float32) if return_trigger_data else None
+        try:
+            self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
+                                    dynamic_threshold_function)
+            new_triggers = list(self._trigger_data[name]["trigger_index"])
+            new_trigger_data = copy.deepcopy(self._trigger_data)
+        finally:        # whatever happens, the first-pass trace goes back (oftrigger.py:824-828)
+            _lib.check(self._lib.ofx_trigger_residual_restore(
+                self._h, res.ctypes.data if res is not None else None, _lib.MEM_HOST, None),
+                "ofx_trigger_residual_restore")
         self._residual_delta_chi2_trace = res
         # combine_trigger_data (oftrigger.py:262-320): second-pass triggers whose index is new
         # are appended; the "<key>_<name>" entries are the same list objects as "<key>"
