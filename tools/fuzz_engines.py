@@ -163,6 +163,7 @@ def run_trigger(cases, seed, verbose=True):
     import test_ofnxm as T
     rng = np.random.default_rng(seed)
     bad = 0
+    extended = 0
     for c in range(cases):
         nxm = bool(rng.integers(0, 2))
         n = 2 * int(rng.integers(32, 1500))              # even: odd trace lengths are rejected
@@ -207,6 +208,30 @@ def run_trigger(cases, seed, verbose=True):
             assert gf.shape == filt.shape, tag + f' shape {gf.shape} vs {filt.shape}'
             assert np.all(np.abs(gf - filt) <= 4e-5 * scale), tag + f' filtered {np.max(np.abs(gf - filt) / scale):.2e}'
             assert np.max(np.abs(gd - dchi)) <= 8e-5 * max(np.max(dchi), 1e-300), tag + ' delta chi2'
+            # dynamic pile-up window and residual pass (padded traces: every trigger is at least
+            # a template length from the edges, where the reference's slices are well defined)
+            dmax = float(np.max(dchi))
+            if padding and dmax > 0 and (not nxm or C == M) and L > 3 * n:
+                thr_s = float(rng.choice([4.0, 6.0]))
+                w0, w1 = float(rng.integers(0, 40)), float(rng.integers(0, n))
+                fn = lambda d: w0 + w1 * min(1.0, d / dmax)
+                ref = tr.find_triggers(thr_s, dynamic_function=fn)
+                g.find_triggers(thr_s, dynamic=True, dynamic_threshold_function=fn)
+                got = g.get_trigger_data()[g._trigger_name]['trigger_index']
+                thr = ref['chi2_threshold']
+                clear = {int(i) for i, d in zip(ref['trigger_index'], ref['trigger_delta_chi2']) if d > 2 * thr + 1e-3 * dmax}
+                assert clear <= set(got), tag + f' dynamic: missing {sorted(clear - set(got))[:5]}'
+                assert abs(len(got) - len(ref['trigger_index'])) <= max(3, len(got) // 5), tag + ' dynamic: count'
+                win = int(rng.integers(0, n))
+                first, second, residual, combined = tr.find_triggers_residual(thr_s, x32.astype(np.float64),
+                                                                              pileup_window_samples=win)
+                out = g.find_triggers(thr_s, pileup_window_samples=win, residual=True, return_trigger_data=True)
+                assert np.max(np.abs(out[3].astype(np.float64) - residual)) <= 2e-4 * dmax, \
+                    tag + f' residual trace {np.max(np.abs(out[3] - residual)) / dmax:.2e}'
+                assert np.array_equal(g.get_filtered_delta_chi2(), gd.astype(np.float32)), tag + ' trace not restored'
+                c2 = {int(i) for i, d in zip(second['trigger_index'], second['trigger_delta_chi2']) if d > 2 * thr + 1e-3 * dmax}
+                assert c2 <= set(out[2][g._trigger_name]['trigger_index']), tag + ' residual: second pass'
+                extended += 1
             g.close()
         except AssertionError as e:
             bad += 1
@@ -216,6 +241,7 @@ def run_trigger(cases, seed, verbose=True):
             print('ERROR', tag); traceback.print_exc()
         if verbose:
             print(tag, 'done', flush=True)
+    print(f'trigger: dynamic window + residual pass checked in {extended} cases', flush=True)
     return bad
 
 
