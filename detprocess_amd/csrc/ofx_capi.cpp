@@ -449,8 +449,16 @@ static int engine_process(ofx_plan* p, const float* d_in, const uint8_t* d_valid
         rc = ofx_lds_process(p, d_in, d_valid, n, d_out, st);
     else
         return ofx_rocfft_process(p, d_in, d_valid, n, d_out, st);
-    if (rc == OFX_ERR_UNSUPPORTED && p->engine_auto)
+    if (rc == OFX_ERR_UNSUPPORTED && p->engine_auto) {
+        // (a FUSED plan of a length the LDS engine carries faster than the rocFFT pipeline, e.g.
+        // 25000 samples, tries that one first)
+        const bool pow2 = (p->N & (p->N - 1)) == 0;
+        if (p->engine == OFX_ENGINE_FUSED && !pow2 && ofx_lds_supported(p->N)) {
+            rc = ofx_lds_process(p, d_in, d_valid, n, d_out, st);
+            if (rc != OFX_ERR_UNSUPPORTED) return rc;
+        }
         rc = ofx_rocfft_process(p, d_in, d_valid, n, d_out, st);
+    }
     return rc;
 }
 

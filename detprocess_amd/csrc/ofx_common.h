@@ -204,6 +204,11 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf);
 int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                       long long n, float* d_out, hipStream_t st);
 int ofx_fused_release(ofx_plan* p);
+// ofx_fused25.hip: the register-resident kernel for 25000-sample traces (dispatched by ofx_fused_*)
+bool ofx_fused25_supported(int n_samples);
+int ofx_fused25_prepare_slot(ofx_plan* p, int slot, const double* wf);
+int ofx_fused25_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
+                        long long n, float* d_out, hipStream_t st);
 bool ofx_lds_supported(int n_samples);
 int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                     long long n, float* d_out, hipStream_t st);

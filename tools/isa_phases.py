@@ -6,7 +6,7 @@ import re,sys
 f = sys.argv[1]
 src = open(f).read().split('\n')
 feat = sys.argv[2] if len(sys.argv) > 2 else '0'
-st = next(i for i,l in enumerate(src) if l.startswith('_ZN12_GLOBAL__N_17k_fusedILi' + feat + 'ELb0E'))
+st = next(i for i,l in enumerate(src) if l.startswith((sys.argv[3] if len(sys.argv) > 3 else '_ZN12_GLOBAL__N_17k_fusedILi') + feat + 'ELb0E'))
 end = next(i for i,l in enumerate(src) if '.amdhsa_kernel' in l and i>st)
 lines = src[st:end]
 def new(): return {'valu':0,'pk':0,'lds':0,'vmem':0,'wait':0,'vm0':0,'salu':0,'bar':0,'scr':0,'smem':0,'rdln':0,'mov':0}
