@@ -15,6 +15,9 @@ region, 32 bytes per event).  Rank 0 prints ONE JSON line.
 --config 3            BASELINE configs[3]: 4 channels x 32768, 3 template tags (pulse / glitch /
                       muon), the feature set of examples/processing/process_example.yaml:109-222
                       through the YAML driver; 262,144 events = 1M traces
+--samples 25000       the same workloads at the trace length of the reference's own example YAML
+                      (examples/processing/process_example.yaml:93; the k_fused25 kernel); the
+                      default 32768 is BASELINE's length and the only one the driver runs
 --stream-events E     BASELINE configs[4] rehearsal on this rank count: E events per GPU consumed
                       in --chunk pieces, generated on a producer stream beside the hot path
                       (run_sharded's streaming form); `value` then includes the generation.
@@ -217,6 +220,7 @@ def metric_name():
 
 
 def main():
+    global N_SAMPLES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -228,9 +232,11 @@ def main():
     ap.add_argument("--stream-events", type=int, default=0,
                     help="events per GPU of a streamed run (configs[4] rehearsal), config 1 only")
     ap.add_argument("--chunk", type=int, default=1 << 19, help="events per chunk when streaming")
+    ap.add_argument("--samples", type=int, default=32768, help="trace length (32768 = BASELINE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
+    N_SAMPLES = args.samples
 
     import torch
     import torch.distributed as dist
@@ -408,7 +414,8 @@ def main():
                                       f"of the feature matrix per pass"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(f"config{args.config}", traces_per_launch),
+                         "traffic": measured_traffic(f"config{args.config}" + ("" if N_SAMPLES == 32768 else f"_n{N_SAMPLES}"),
+                                                     traces_per_launch),
                          "kernel_ms": k_ms, "launches": k_n,
                          "traces_per_launch": traces_per_launch,
                          "algorithmic_bytes_per_trace": algo_bytes},

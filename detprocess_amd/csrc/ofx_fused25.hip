@@ -447,26 +447,54 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             }
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-                float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
+                // sums of rounds 0, 1 (sa, sqa: masked by `act` at the end -- idle lanes are mirrors)
+                // and of round 2 (sb, sqb: masked by `act3`); duplicates do not change max / min
+                float sa = 0.0f, sqa = 0.0f, sb = 0.0f, sqb = 0.0f, mx = -INFINITY, mn = INFINITY;
+                cpx s2a = mk(0.0f, 0.0f), sq2a = mk(0.0f, 0.0f), s2b = mk(0.0f, 0.0f), sq2b = mk(0.0f, 0.0f);
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1) {
                     const int r0 = ROWS * n1;
                     if (r0 + ROWS <= lo || r0 >= hi) continue;            // uniform: outside
+                    if (lo <= r0 && r0 + ROWS <= hi) {                    // uniform: full row
 #pragma unroll
-                    for (int h = 0; h < 3; ++h) {
-                        if (h == 2 && !w2) continue;                       // uniform
-                        const int n = r0 + 2 * (h == 2 ? vt3 : tc + GT * h);
-                        const bool on = (h == 2) ? act3 : act;
-                        const bool in0 = on && (n >= lo) && (n < hi);
-                        const bool in1 = on && (n + 1 >= lo) && (n + 1 < hi);
-                        const cpx v = d[R1 * h + n1];
-                        const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
-                        s = (s + y0) + y1;
-                        sq = fmaf(y0, y0, fmaf(y1, y1, sq));
-                        mx = max3f(mx, in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY);
-                        mn = min3f(mn, in0 ? v.x : INFINITY, in1 ? v.y : INFINITY);
+                        for (int h = 0; h < 2; ++h) {
+                            // (dependent forms only, as in ofx_fused.hip)
+                            const cpx v = d[R1 * h + n1];
+                            s2a = s2a + v;
+                            sq2a = pfma(v, v, sq2a);
+                            mx = max3f(mx, v.x, v.y);
+                            mn = min3f(mn, v.x, v.y);
+                        }
+                        if (w2) {
+                            const cpx v = d[2 * R1 + n1];
+                            s2b = s2b + v;
+                            sq2b = pfma(v, v, sq2b);
+                            mx = max3f(mx, v.x, v.y);
+                            mn = min3f(mn, v.x, v.y);
+                        }
+                    } else {                                              // edge row
+#pragma unroll
+                        for (int h = 0; h < 3; ++h) {
+                            if (h == 2 && !w2) continue;                   // uniform
+                            const int n = r0 + 2 * (h == 2 ? vt3 : tc + GT * h);
+                            const bool in0 = (n >= lo) && (n < hi);
+                            const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                            const cpx v = d[R1 * h + n1];
+                            const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
+                            if (h == 2) {
+                                sb = (sb + y0) + y1;
+                                sqb = fmaf(y0, y0, fmaf(y1, y1, sqb));
+                            } else {
+                                sa = (sa + y0) + y1;
+                                sqa = fmaf(y0, y0, fmaf(y1, y1, sqa));
+                            }
+                            mx = max3f(mx, in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY);
+                            mn = min3f(mn, in0 ? v.x : INFINITY, in1 ? v.y : INFINITY);
+                        }
                     }
                 }
+                float s = (act ? sa + (s2a.x + s2a.y) : 0.0f) + (act3 ? sb + (s2b.x + s2b.y) : 0.0f);
+                float sq = (act ? sqa + (sq2a.x + sq2a.y) : 0.0f) + (act3 ? sqb + (sq2b.x + sq2b.y) : 0.0f);
                 s = ofx_wave_sum(s);
                 sq = ofx_wave_sum(sq);
                 mx = ofx_wave_max(mx);
@@ -677,9 +705,11 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         STAMP(8);
         {
             const int vt3b = min(tl2 + 2 * GT, NV1 - 1);
+#ifdef OFX25_ANCH_EARLY
             const T1Anch g0 = t1_load(t1q, tc2);
             const T1Anch g1 = t1_load(t1q, tc2 + GT);
             __builtin_amdgcn_sched_barrier(0);
+#endif
             // ------------------------------------------------------------ E4
 #if OFX_XPRIO
             __builtin_amdgcn_s_setprio(OFX_XPRIO);
@@ -707,6 +737,10 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 #endif
             STAMP(9);
             // ------------------------------------------------------------ I1
+#ifndef OFX25_ANCH_EARLY
+            const T1Anch g0 = t1_load(t1q, tc2);
+            const T1Anch g1 = t1_load(t1q, tc2 + GT);
+#endif
             t1_apply<true, 0>(d, g0);
             t1_apply<true, R1>(d, g1);
             dft20<+1, NV, 0>(d);

@@ -38,7 +38,7 @@ def test_oracle_reproduces_golden(name):
 
 
 def _engines_for(n):
-    return ["fused", "rocfft", "lds"] if n == 32768 else ["rocfft", "lds"]
+    return ["fused", "rocfft", "lds"] if n in (32768, 25000) else ["rocfft", "lds"]
 
 
 @pytest.mark.gpu

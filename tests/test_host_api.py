@@ -446,8 +446,8 @@ Melange025pcLeft|Melange025pcRight:
 def test_example_shaped_config_at_25000_samples():
     """A configuration shaped like the reference's example (20 ms traces at 1.25 MHz = 25000
     samples, comma-separated channel blocks, a summed channel, psd_amp, a 2x2 ``a|b`` block
-    and an algorithm outside this engine): of1x1 runs on the LDS engine, ofnxm on the NxM
-    engine, through the YAML driver."""
+    and an algorithm outside this engine): of1x1 runs on the FUSED engine (k_fused25), ofnxm on
+    the NxM engine, through the YAML driver."""
     from detprocess_amd import FeatureProcessing
     from oracle import of1x1 as orc
     from oracle import ofnxm as onm
@@ -468,7 +468,7 @@ def test_example_shaped_config_at_25000_samples():
     with pytest.warns(UserWarning, match="outside the hot path"):
         fp = FeatureProcessing(YAML_25000, fd, CHANS, FS, skip_unsupported=True)
         df = fp.process(ev)
-    assert {cp.plan.engine for cp in fp._plans.values() if not getattr(cp, "nxm", False)} == {"lds"}
+    assert {cp.plan.engine for cp in fp._plans.values() if not getattr(cp, "nxm", False)} == {"fused"}
     # the 2x2 block: windowed delay fit + no-delay fit, named as algorithms.py:229-273
     fn = onm.NxMFilter(t2, c2, FS, pre)
     rn = onm.process_events(fn, ev[:, 1:3, :].astype(np.float64), window_min_from_trig_usec=-100,

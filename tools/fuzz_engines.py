@@ -245,16 +245,16 @@ def run_trigger(cases, seed, verbose=True):
     return bad
 
 
-def run_fused(cases, seed, verbose=True):
-    """The FUSED kernel at 32768 samples under random plans (1-3 template tags, no-delay /
+def run_fused(cases, seed, verbose=True, n=32768):
+    """The FUSED kernel at 32768 samples (mode 'fused') or 25000 samples (mode 'fused25', k_fused25) under random plans (1-3 template tags, no-delay /
     full / windowed / outside / interpolated fits, 0-3 time-domain windows, channel sums with
     weights, valid masks, batches below and above the persistent grid) against the ROCFFT
     engine on every event and against the oracle on a few."""
     rng = np.random.default_rng(seed)
-    n, bad = 32768, 0
+    bad = 0
     psd = synth.make_psd(n, FS)
     for c in range(cases):
-        pre = int(rng.choice([16384, 16384, int(rng.integers(4096, 28000))]))
+        pre = int(rng.choice([n // 2, n // 2, int(rng.integers(n // 8, n - n // 8))]))
         kinds = ['pulse', 'glitch', 'muon'][: int(rng.integers(1, 4))]
         tmpls = [synth.make_template(n, pre, FS, k) for k in kinds]
         fts = [build_filter(t, psd, FS, pre) for t in tmpls]
@@ -280,7 +280,8 @@ def run_fused(cases, seed, verbose=True):
         tdw = []
         for _ in range(int(rng.integers(0, 4))):
             lo = int(rng.integers(0, n - 2)); tdw.append((lo, int(rng.integers(lo + 1, n))))
-        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, 120000.0]))     # beyond 512 bins: the stash
+        # beyond 512 bins: the stash (32768 samples); 25000 samples: up to the 1250 bins kept in LDS
+        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, 120000.0 if n == 32768 else 62000.0]))
         tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)} fcut={fcut_c}'
         outs = {}
         try:
@@ -420,6 +421,8 @@ if __name__ == '__main__':
         bad = run_trigger(cases, seed)
     elif len(sys.argv) > 3 and sys.argv[3] == 'fused':
         bad = run_fused(cases, seed)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'fused25':
+        bad = run_fused(cases, seed, n=25000)
     elif len(sys.argv) > 3 and sys.argv[3] == 'adc':
         bad = run_adc(cases, seed)
     else:
