@@ -59,6 +59,15 @@ constexpr int VPAD = 256;               // table row length (threads)
 constexpr int T1PAD = 640;              // anchor table row length (virtual threads of F1)
 constexpr int NWAVE = BLK / OFX_WAVE;
 constexpr int WG_PER_CU = 2;
+// The third round of I1 / the tail (virtual threads 500..624) sits in the waves from I3W on:
+// 0 = waves 0, 1 as in F1; 2 = waves 2, 3, so that over a whole trace every wave -- every SIMD,
+// which hosts the same wave of both resident workgroups -- carries five rounds of 20-point
+// transforms instead of six on SIMDs 0, 1 and four on SIMDs 2, 3.
+#ifndef OFX25_I3W
+#define OFX25_I3W 0
+#endif
+constexpr int I3W = OFX25_I3W;
+constexpr int I3T = 64 * I3W;           // first thread of the inverse third round
 static_assert(XB_ELEMS >= GT * R3 && XB_ELEMS * 2 >= GM, "exchange buffer");
 
 #ifndef OFX_XPRIO
@@ -91,7 +100,31 @@ struct Lds25 {
 constexpr size_t LDS_BYTES = sizeof(Shared25) + sizeof(Lds25);
 static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
 
+#ifndef OFX_STAMPS
 #define STAMP(i) asm volatile(";ofxphase " #i)
+#define SUBSTAMP(i)
+#else
+#define SUBSTAMP(i) STAMP(i)
+// Diagnostic build (-DOFX_STAMPS, tools/phase_timeline.py --n25000): as in ofx_fused.hip, every
+// wave writes the shader clock at every phase marker of its first OFX_STAMP_TRACES traces with
+// scalar stores ([workgroup][trace][wave][16]; the buffer is passed in place of `spec`).
+#define OFX_STAMP_TRACES 40
+__device__ __forceinline__ void ofx_stamp(unsigned long long* p) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0"
+                 : "=&s"(t) : "s"(p));
+}
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        asm volatile(";ofxphase " #i);                                                        \
+        {                                                                                     \
+            const int si_ = stamp_it < OFX_STAMP_TRACES - 1 ? stamp_it : OFX_STAMP_TRACES - 1; \
+            unsigned long long* sb_ = stamp_base + (size_t)si_ * (NWAVE * 16);                \
+            ofx_stamp(sb_ + (i));                                                             \
+            if ((i) == 12) ++stamp_it;                                                        \
+        }                                                                                     \
+    } while (0)
+#endif
 
 struct Tabs25 {
     const float2* t1;     // [4][640] float4 rows of stage-1 twiddle anchors
@@ -312,6 +345,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
     const int tid = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool w2 = wave < 2;                       // waves holding a third F1 virtual thread
+    const bool w2i = (I3W == 0) ? w2 : !w2;         // ... and a third I1 virtual thread
     const int pre = pd.pre;
     const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 4 * T1PAD * 16);
     const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, VPAD * 8);
@@ -407,6 +441,17 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
     auto pass2 = [](int h, int k2) { return k2 < 12 ? 0 : (k2 > 12 ? 1 : h); };
 
     bool have = false;
+#ifdef OFX_STAMPS
+    int stamp_it = 0;
+    unsigned long long* stamp_base;
+    {
+        const size_t off = (((size_t)blockIdx.x * OFX_STAMP_TRACES) * NWAVE + (size_t)wave) * 16;
+        const unsigned long long a = reinterpret_cast<unsigned long long>(spec) + off * 8;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        stamp_base = reinterpret_cast<unsigned long long*>(((unsigned long long)hi << 32) | lo);
+    }
+#endif
     const long long stride = (long long)gridDim.x;
     for (long long b = (long long)blockIdx.x; b < n_traces; b += stride) {
         float* row = out + (size_t)b * pd.row;
@@ -704,12 +749,13 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         dft25<+1, NV, R2>(d);
         STAMP(8);
         {
-            const int vt3b = min(tl2 + 2 * GT, NV1 - 1);
-#ifdef OFX25_ANCH_EARLY
+            const int vt3b = min(max(tl2 - I3T, 0) + 2 * GT, NV1 - 1);
+            // anchors of the stage-1 twiddles: requested ahead of the exchange (L2 latency)
             const T1Anch g0 = t1_load(t1q, tc2);
             const T1Anch g1 = t1_load(t1q, tc2 + GT);
+            T1Anch g2;
+            if (w2i) g2 = t1_load(t1q, vt3b);
             __builtin_amdgcn_sched_barrier(0);
-#endif
             // ------------------------------------------------------------ E4
 #if OFX_XPRIO
             __builtin_amdgcn_s_setprio(OFX_XPRIO);
@@ -725,7 +771,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 #pragma unroll
                     for (int j = 0; j < HR1; ++j)
                         nd[R1 * h + HR1 * p + j] = xc[j * LD1 + tc2 + GT * h];
-                if (w2) {
+                if (w2i) {
 #pragma unroll
                     for (int j = 0; j < HR1; ++j) nd[2 * R1 + HR1 * p + j] = xc[j * LD1 + vt3b];
                 }
@@ -737,18 +783,13 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 #endif
             STAMP(9);
             // ------------------------------------------------------------ I1
-#ifndef OFX25_ANCH_EARLY
-            const T1Anch g0 = t1_load(t1q, tc2);
-            const T1Anch g1 = t1_load(t1q, tc2 + GT);
-#endif
             t1_apply<true, 0>(d, g0);
             t1_apply<true, R1>(d, g1);
             dft20<+1, NV, 0>(d);
             dft20<+1, NV, R1>(d);
-            if (w2) {
+            if (w2i) {
 #pragma unroll
                 for (int j = 2 * R1; j < NV; ++j) d[j] = nd[j];
-                const T1Anch g2 = t1_load(t1q, vt3b);
                 t1_apply<true, 2 * R1>(d, g2);
                 dft20<+1, NV, 2 * R1>(d);
             } else {
@@ -778,7 +819,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         const int lane_t = tt & 63, wave_t = tt >> 6;
         const bool act_t = tt < GT;
         const int tct = min(tt, GT - 1);
-        const int vt3t = min(tt + 2 * GT, NV1 - 1);
+        const int vt3t = min(max(tt - I3T, 0) + 2 * GT, NV1 - 1);
         const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(SDX.s, NLOW_MAX * 8);
         const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(SDX.g, NLOW_MAX * 4);
         constexpr int GS = 10;                     // registers per group (two groups per round)
@@ -796,6 +837,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             gm[g] = m;
             mloc = fmaxf(mloc, m);
         }
+        // low-frequency chi2 tables for this thread's bins: requested now, used at the end
         constexpr int NLK = NLOW_MAX / GT;         // 5 low bins per thread
         cpx lk_s[NLK];
         float lk_g[NLK];
@@ -805,40 +847,20 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             lk_s[i] = buf_ld2(rs_s, k * 8, 0);
             lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, k * 4, 0, 0));
         }
+        // One reduction for the maximum, its rolled index and chi2_0: every wave resolves the
+        // smallest rolled index among ITS lags of maximal A^2 (the lanes that hold the wave's
+        // maximum search only the matching group of registers), the four candidates meet in LDS
+        // behind a single barrier.  (L.cand / L.red were last read in the previous tail, at least
+        // four exchange barriers ago: no barrier in front of the writes.)
+        OfxCand fullbest = ofx_cand_none();
         {
             const float wmax = ofx_wave_max(mloc);
-            const float wchi = ofx_wave_sum(chi0p);
-            __syncthreads();
-            if (lane_t == 0) {
-                L.red[0][wave_t] = wmax;
-                L.red[1][wave_t] = wchi;
-            }
-            if (tt == 0) L.bcast[0] = d[0].x;          // A(lag 0)
-            __syncthreads();
-        }
-        float Mstar = L.red[0][0], chi0 = L.red[1][0];
-#pragma unroll
-        for (int q = 1; q < NWAVE; ++q) {
-            Mstar = fmaxf(Mstar, L.red[0][q]);
-            chi0 += L.red[1][q];
-        }
-        float a_lag0 = L.bcast[0];
-        asm volatile("" : "+v"(Mstar), "+v"(chi0), "+v"(a_lag0));
-
-        OfxCand fullbest = ofx_cand_none();
-        bool any_full = false;
-#pragma unroll 1
-        for (int q = 0; q < SDX.n_search; ++q) {
-            const OfxSearchDev& sq = SDX.search[q];
-            any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 && sq.hi == GN;
-        }
-        if (any_full) {
-            if (mloc == Mstar) {
+            if (mloc == wmax) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    if (__builtin_amdgcn_ballot_w64(gm[g] == Mstar) == 0) continue;   // uniform
+                    if (__builtin_amdgcn_ballot_w64(gm[g] == wmax) == 0) continue;    // uniform
                     const int h = (GS * g) / R1;
-                    if (h == 2 && !w2) continue;                                      // zeros
+                    if (h == 2 && !w2i) continue;                                     // zeros
                     const int base = 2 * (h == 2 ? vt3t : tct + GT * h) + pre;
 #pragma unroll
                     for (int j = GS * g; j < GS * g + GS; ++j) {
@@ -848,17 +870,36 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                         i0 = i0 >= GN ? i0 - GN : i0;
                         int i1 = i0 + 1;
                         i1 = i1 >= GN ? i1 - GN : i1;
-                        if (v.x * v.x == Mstar && i0 < fullbest.idx) {
-                            fullbest.idx = i0; fullbest.amp = v.x; fullbest.key = Mstar;
+                        if (v.x * v.x == wmax && i0 < fullbest.idx) {
+                            fullbest.idx = i0; fullbest.amp = v.x; fullbest.key = wmax;
                         }
-                        if (v.y * v.y == Mstar && i1 < fullbest.idx) {
-                            fullbest.idx = i1; fullbest.amp = v.y; fullbest.key = Mstar;
+                        if (v.y * v.y == wmax && i1 < fullbest.idx) {
+                            fullbest.idx = i1; fullbest.amp = v.y; fullbest.key = wmax;
                         }
                     }
                 }
             }
-            fullbest = ofx_cand_block_reduce(fullbest, L.cand, tt, NWAVE);
+            fullbest = ofx_cand_wave_reduce(fullbest);
+            const float wchi = ofx_wave_sum(chi0p);
+            if (lane_t == 0) {
+                L.cand[wave_t] = fullbest;
+                L.red[1][wave_t] = wchi;
+            }
+            if (tt == 0) L.bcast[0] = d[0].x;          // A(lag 0)
+            __syncthreads();
         }
+        float chi0 = L.red[1][0];
+        fullbest = L.cand[0];
+#pragma unroll
+        for (int q = 1; q < NWAVE; ++q) {
+            const OfxCand o = L.cand[q];
+            if (ofx_cand_better(o.key, o.idx, fullbest)) fullbest = o;
+            chi0 += L.red[1][q];
+        }
+        float a_lag0 = L.bcast[0];
+        asm volatile("" : "+v"(chi0), "+v"(a_lag0));
+        SUBSTAMP(13);
+        SUBSTAMP(14);
 
         // windowed / outside-window fits scan the lag dump: even lags, then odd lags
         if constexpr (FEAT & 1) {
@@ -867,7 +908,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                 __syncthreads();
 #pragma unroll
                 for (int h = 0; h < 3; ++h) {
-                    if (h == 2 && !w2) continue;
+                    if (h == 2 && !w2i) continue;
                     const int vth = (h == 2) ? vt3t : tct + GT * h;
 #pragma unroll
                     for (int n1 = 0; n1 < R1; ++n1)
@@ -953,7 +994,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                     const int n1 = n / ROWS;
                     const int vt_n = (n - ROWS * n1) >> 1;
                     const int hh = vt_n / GT;
-                    if (best.idx != 0x7fffffff && tt == vt_n - GT * hh) {
+                    if (best.idx != 0x7fffffff && tt == vt_n - GT * hh + (hh == 2 ? I3T : 0)) {
                         const int jn = R1 * hh + n1;
                         cpx v = d[0];
 #pragma unroll
@@ -968,45 +1009,53 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             }
             __syncthreads();
         }
-#pragma unroll 1
-        for (int q = 0; q < SDX.n_search; ++q) {
-            const OfxSearchDev& sq = SDX.search[q];
-            const OfxCand best = resolve(sq, q);
-            const int dl = best.idx - pre;
-            OfxRefined ref;
-            ref.amp = best.amp;
-            ref.frac = 0.0f;
-            ref.chi2 = 0.0f;
-            if constexpr (FEAT & 1)
-                if (sq.interp) ref = L.ref[q];
-            float low = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NLK; ++i) {
-                const int k = tt + GT * i;
-                if (act_t && k < sq.nlow)
-                    low += lowchi2_term(k, dl, ref.amp, L.xlow[k], lk_s[i], lk_g[i], ref.frac);
-            }
-            low = ofx_wave_sum(low);
-            if (lane_t == 0) L.lowp[q][wave_t] = low;
-            if (tt == 0) L.fin[q] = best;
-        }
-        STAMP(11);
-        __syncthreads();
-        if (tt < SDX.n_search) {
-            const int q = tt;
-            float lw = 0.0f;
-            for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
-            const OfxRefined* rp = nullptr;
-            if constexpr (FEAT & 1)
-                if (SDX.search[q].interp) rp = &L.ref[q];
-            ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
-        }
+        SUBSTAMP(15);
+        // d and the time-domain temporaries are dead: the request of the next trace (or of the
+        // spectrum again, for the next slot)
+        // (one request site, ahead of the low-frequency chi2: its HBM latency hides under the terms
+        // below; the tables of those terms were requested before it, so that waiting for them --
+        // vmcnt counts in order -- does not wait for the trace)
         if (MULTI && slot_i + 1 < slot_n) {
             load_spec();
         } else {
             const long long bn = b + stride;
             have = bn < n_traces;
             if (have) load_trace(bn);
+        }
+        {
+#pragma unroll 1
+            for (int q = 0; q < SDX.n_search; ++q) {
+                const OfxSearchDev& sq = SDX.search[q];
+                const OfxCand best = resolve(sq, q);
+                const int dl = best.idx - pre;
+                OfxRefined ref;
+                ref.amp = best.amp;
+                ref.frac = 0.0f;
+                ref.chi2 = 0.0f;
+                if constexpr (FEAT & 1)
+                    if (sq.interp) ref = L.ref[q];
+                float low = 0.0f;
+#pragma unroll
+                for (int i = 0; i < NLK; ++i) {
+                    const int k = tt + GT * i;
+                    if (act_t && k < sq.nlow)
+                        low += lowchi2_term(k, dl, ref.amp, L.xlow[k], lk_s[i], lk_g[i], ref.frac);
+                }
+                low = ofx_wave_sum(low);
+                if (lane_t == 0) L.lowp[q][wave_t] = low;
+                if (tt == 0) L.fin[q] = best;
+            }
+            STAMP(11);
+            __syncthreads();
+            if (tt < SDX.n_search) {
+                const int q = tt;
+                float lw = 0.0f;
+                for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
+                const OfxRefined* rp = nullptr;
+                if constexpr (FEAT & 1)
+                    if (SDX.search[q].interp) rp = &L.ref[q];
+                ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
+            }
         }
         }
 #undef SDX
@@ -1016,6 +1065,9 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 #endif
         STAMP(12);
     }
+#ifdef OFX_STAMPS
+    asm volatile("s_dcache_wb");
+#endif
 }
 
 }  // namespace
@@ -1115,6 +1167,14 @@ static int launch25(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, con
         }
     }
     if (grid > n) grid = n;
+#ifdef OFX_STAMPS
+    const size_t stamp_bytes = (size_t)grid * OFX_STAMP_TRACES * NWAVE * 16 * sizeof(unsigned long long);
+    if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
+    p->d_fused_spec = nullptr;
+    p->fused_spec_bytes = 0;
+    OFX_HIP(hipMalloc(&p->d_fused_spec, stamp_bytes));
+    OFX_HIP(hipMemset(p->d_fused_spec, 0, stamp_bytes));
+#endif
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
@@ -1124,6 +1184,17 @@ static int launch25(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, con
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
+#ifdef OFX_STAMPS
+    if (const char* f = getenv("OFX_STAMP_FILE")) {
+        OFX_HIP(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h(stamp_bytes / 8);
+        OFX_HIP(hipMemcpy(h.data(), p->d_fused_spec, stamp_bytes, hipMemcpyDeviceToHost));
+        if (FILE* fp = fopen(f, "wb")) {
+            fwrite(h.data(), 8, h.size(), fp);
+            fclose(fp);
+        }
+    }
+#endif
     return OFX_OK;
 }
 

@@ -132,7 +132,42 @@ def overlap(a):
             'one_in_valu_phase': float(r[:, 1].mean()), 'both_in_valu_phase': float(r[:, 2].mean())}
 
 
+def run25(n, path):
+    """k_fused25 (25000 samples; make variant NAME=f25_stamps VARSRC=ofx_fused25.hip
+    EXTRA='-DOFX_QUICK -DOFX_STAMPS'): stamps of every wave."""
+    env = dict(os.environ, OFX_STAMP_FILE=path)
+    code = f'''
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from detprocess_amd import OFPlan, build_filter, synth, SynthSource
+N=25000; fs=1.25e6; pre=N//2
+tmpl=synth.make_template(N,pre,fs); psd=synth.make_psd(N,fs); ft=build_filter(tmpl,psd,fs,pre)
+gen=SynthSource(N,tmpl,psd,fs,3*ft.ampres,300*ft.ampres,0.5,2000,seed=1)
+x=torch.empty(({n},N),dtype=torch.float32,device='cuda:0'); gen.fill(0,{n},x)
+plan=OFPlan(N,pre,fs,max_batch=8192,engine='fused'); plan.set_filter(0,ft); plan.add_search(0,'delay')
+for _ in range(3): plan.process(x)
+torch.cuda.synchronize()
+'''
+    subprocess.run([sys.executable, '-c', code], env=env, check=True)
+    return np.fromfile(path, dtype=np.uint64).reshape(-1, NT, NW, 16)
+
+
 if __name__ == '__main__':
+    if '--n25000' in sys.argv:
+        sys.argv.remove('--n25000')
+        a = run25(int(sys.argv[1]) if len(sys.argv) > 1 else 65536, '/tmp/stamps25.bin')
+        rep = {f'cycles_per_phase_wave{w}': summarise(a[:, :, w, :]) for w in range(NW)}
+        json.dump(rep, open(sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline_25000.json', 'w'), indent=1)
+        for k in PH[1:] + ['loop', 'total']:
+            print(f'{k:8s} ' + '  '.join(f"w{w} {rep[f'cycles_per_phase_wave{w}'][k]:8.0f}" for w in range(NW)))
+        # sub-stamps of the tail: 10 -> 13 (max, first reduction) -> 14 (arg-max) -> 15 (windows, bands) -> 11 (lowchi2)
+        tt = a[:, 6:NT - 3, :, :].astype(np.int64)
+        ok = (tt[..., 12] > 0) & (tt[..., 13] > 0)
+        seq = [10, 13, 14, 15, 11]
+        for i in range(4):
+            dd = (tt[..., seq[i + 1]] - tt[..., seq[i]])
+            print(f'tail {seq[i]:2d}->{seq[i + 1]:2d} ' + '  '.join(f'w{w} {dd[:, :, w][ok[:, :, w]].mean():8.0f}' for w in range(NW)))
+        sys.exit(0)
     if '--config2' in sys.argv:
         sys.argv.remove('--config2')
         a2 = run(int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 2, '/tmp/stamps2c.bin', config3=2)
