@@ -127,7 +127,7 @@ __device__ __forceinline__ void ofx_stamp(unsigned long long* p) {
 #endif
 
 struct Tabs25 {
-    const float2* t1;     // [4][640] float4 rows of stage-1 twiddle anchors
+    const float2* t1;     // [2][640] float4 rows of stage-1 twiddle anchors
     const float2* t2;     // [25][25]   w_625^{n3 k2}
     const float4* midW;   // [25][256]  (W_k / 2, conj(W_p) / 2)   slot J, thread v
     const float2* midG;   // [25][256]  (g_k', g_p')
@@ -276,32 +276,35 @@ __device__ __forceinline__ cpx middle_slots(cpx (&d)[NV], const MidRsrc& r, int 
     return chi;
 }
 
-// Inter-stage twiddles w_M^{n' k1}, k1 = 5 a + b, from seven anchors per virtual thread:
-// B_b = w^{n' b} (b = 1..4), A_a = w^{5 n' a} (a = 1..3).  t1a[r][n'] = (anchor 2r, 2r+1),
-// anchors ordered B1..B4, A1..A3.
+// Inter-stage twiddles w_M^{n' k1}, k1 = 5 a + b = 0..19, from four anchors per virtual thread:
+// B1 = w^{n'}, B2 = w^{2 n'}, A1 = w^{5 n'}, A2 = w^{10 n'} (32 bytes, one L2 round trip);
+// B3 = B1 B2, B4 = B2 B2, A3 = A1 A2, w^{n' (5 a + b)} = A_a B_b: at most three roundings on top
+// of the table's.  (Seven tabulated anchors cost 16 registers per round of virtual threads, and
+// with three rounds in flight around E4 the third set was spilled.)  t1a[0][n'] = (B1, B2),
+// t1a[1][n'] = (A1, A2).
 struct T1Anch {
-    float4 q[4];
+    float4 q[2];
 };
 __device__ __forceinline__ T1Anch t1_load(__amdgpu_buffer_rsrc_t t1a, int vt) {
     T1Anch r;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) r.q[c] = buf_ld4(t1a, vt * 16, c * T1PAD * 16);
+    for (int c = 0; c < 2; ++c) r.q[c] = buf_ld4(t1a, vt * 16, c * T1PAD * 16);
     return r;
 }
 template <bool CONJ, int O>
 __device__ __forceinline__ void t1_apply(cpx (&d)[NV], const T1Anch& an) {
 #ifdef ABL_NOFFT
-    d[O] = d[O] + lo2(an.q[0]) + lo2(an.q[3]);
+    d[O] = d[O] + lo2(an.q[0]) + lo2(an.q[1]);
     return;
 #endif
     cpx B[5], A[4];
     B[1] = lo2(an.q[0]);
     B[2] = hi2(an.q[0]);
-    B[3] = lo2(an.q[1]);
-    B[4] = hi2(an.q[1]);
-    A[1] = lo2(an.q[2]);
-    A[2] = hi2(an.q[2]);
-    A[3] = lo2(an.q[3]);
+    B[3] = cmul(B[1], B[2]);
+    B[4] = cmul(B[2], B[2]);
+    A[1] = lo2(an.q[1]);
+    A[2] = hi2(an.q[1]);
+    A[3] = cmul(A[1], A[2]);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
     const bool w2 = wave < 2;                       // waves holding a third F1 virtual thread
     const bool w2i = (I3W == 0) ? w2 : !w2;         // ... and a third I1 virtual thread
     const int pre = pd.pre;
-    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 4 * T1PAD * 16);
+    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 2 * T1PAD * 16);
     const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, VPAD * 8);
 
     for (int i = tid; i < R2 * R3; i += BLK) SH.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
@@ -753,8 +756,6 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             // anchors of the stage-1 twiddles: requested ahead of the exchange (L2 latency)
             const T1Anch g0 = t1_load(t1q, tc2);
             const T1Anch g1 = t1_load(t1q, tc2 + GT);
-            T1Anch g2;
-            if (w2i) g2 = t1_load(t1q, vt3b);
             __builtin_amdgcn_sched_barrier(0);
             // ------------------------------------------------------------ E4
 #if OFX_XPRIO
@@ -771,9 +772,11 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 #pragma unroll
                     for (int j = 0; j < HR1; ++j)
                         nd[R1 * h + HR1 * p + j] = xc[j * LD1 + tc2 + GT * h];
-                if (w2i) {
+                // (third round: the rows of pass 1 stay in the buffer until the next barrier and
+                // are read when their turn comes in I1 -- ten values less to hold meanwhile)
+                if (p == 0 && w2i) {
 #pragma unroll
-                    for (int j = 0; j < HR1; ++j) nd[2 * R1 + HR1 * p + j] = xc[j * LD1 + vt3b];
+                    for (int j = 0; j < HR1; ++j) nd[2 * R1 + j] = xc[j * LD1 + vt3b];
                 }
             }
 #pragma unroll
@@ -785,11 +788,19 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             // ------------------------------------------------------------ I1
             t1_apply<true, 0>(d, g0);
             t1_apply<true, R1>(d, g1);
+            // (the third round's anchors: requested once those of the first two are dead, ahead
+            // of the two transforms)
+            T1Anch g2 = g1;       // (defined on every path: an undefined value is carried around the loop)
+            if (w2i) g2 = t1_load(t1q, vt3b);
+            __builtin_amdgcn_sched_barrier(0);
             dft20<+1, NV, 0>(d);
             dft20<+1, NV, R1>(d);
             if (w2i) {
 #pragma unroll
-                for (int j = 2 * R1; j < NV; ++j) d[j] = nd[j];
+                for (int j = 0; j < HR1; ++j) {
+                    d[2 * R1 + j] = nd[2 * R1 + j];
+                    d[2 * R1 + HR1 + j] = xc[j * LD1 + vt3b];
+                }
                 t1_apply<true, 2 * R1>(d, g2);
                 dft20<+1, NV, 2 * R1>(d);
             } else {
@@ -1078,9 +1089,9 @@ bool ofx_fused25_supported(int n_samples) { return n_samples == GN; }
 static int fused25_tables(ofx_plan* p) {
     if (p->d_tw1) return OFX_OK;
     const double PI2 = 6.283185307179586476925286766559;
-    std::vector<float2> t1(8 * T1PAD, make_float2(1.0f, 0.0f)), t2(R2 * R3 + VPAD);
-    const int anchor_mult[8] = {1, 2, 3, 4, 5, 10, 15, 0};    // B1..B4, A1..A3, unused
-    for (int i = 0; i < 8; ++i)
+    std::vector<float2> t1(4 * T1PAD, make_float2(1.0f, 0.0f)), t2(R2 * R3 + VPAD);
+    const int anchor_mult[4] = {1, 2, 5, 10};                 // B1, B2, A1, A2
+    for (int i = 0; i < 4; ++i)
         for (int n = 0; n < T1PAD; ++n) {
             const long long e = ((long long)anchor_mult[i] * n) % GM;
             const double a = -PI2 * (double)e / GM;
