@@ -2,7 +2,8 @@
 muon), the full per-channel feature set of the reference's example
 (examples/processing/process_example.yaml:109-222, lowchi2_fcutoff 50 kHz), driven through
 ``FeatureProcessing`` -- the same YAML text ``bench.py --config 3`` runs -- and checked column by
-column against the oracle.  Every plan must stay on the FUSED kernel."""
+column against the oracle.  Every plan must stay on the FUSED kernel.  The same at the example's
+own trace length, 25000 samples (process_example.yaml:93; k_fused25)."""
 
 import os
 import sys
@@ -18,12 +19,14 @@ pytestmark = pytest.mark.gpu
 FS = 1.25e6
 
 
-def test_four_channels_three_tags_full_yaml_set_on_the_fused_kernel():
+@pytest.mark.parametrize("n", [32768, 25000])
+def test_four_channels_three_tags_full_yaml_set_on_the_fused_kernel(n, monkeypatch):
     import bench
     from detprocess_amd import FeatureProcessing
     from oracle import of1x1 as orc
     from util import AMP_ATOL_SIGMA, AMP_RTOL, CHI_ATOL_CHI0, CHI_RTOL
-    n, pre, B = 32768, 16384, 10
+    monkeypatch.setattr(bench, "N_SAMPLES", n)
+    pre, B = n // 2, 10
     fd = bench.filter_data3(pre)
     J = synth.make_psd(n, FS)
     filts = {t: orc.OFFilter(synth.make_template(n, pre, FS, t), J, FS, pre) for t in bench.TAGS3}

@@ -62,7 +62,7 @@ if __name__ == '__main__':
                      'of1x1_unconstrained, relative errors over the events whose t0 bin matches; amp relative to '
                      'max(|amp|, ampres)',
            'n32768': report(32768, ('fused', 'rocfft'), B),
-           'n25000': report(25000, ('lds', 'rocfft'), B // 2),
+           'n25000': report(25000, ('fused', 'lds', 'rocfft'), B // 2),
            'n4096': report(4096, ('lds', 'rocfft'), B)}
     json.dump(rep, open(dest, 'w'), indent=1)
     print('written', dest)
