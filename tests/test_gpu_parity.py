@@ -385,15 +385,16 @@ def test_argument_errors_surface_as_exceptions():
         plan.add_search(5, "delay")                    # slot without a filter
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("n", [32768, 25000])
+def test_full_size_properties(n):
     """Size-independent properties at BASELINE.json's full size: 1,048,576
     device-generated events x 32768 samples (137 GB resident; scaled down if the
-    card has less free memory):
+    card has less free memory), and the same at the reference example's 25000 samples (k_fused25):
     fused == rocfft bin for bin; injected pulses come back; linearity (x2 -> amp
     x2, same bin, chi2 x4); circular-shift equivariance; idempotence."""
     import torch
     from detprocess_amd import OFPlan, synth_traces
-    n, pre, B = 32768, 16384, 1 << 20
+    pre, B = n // 2, 1 << 20
     free, _ = torch.cuda.mem_get_info(0)
     B = min(B, int((free - (24 << 30)) // (n * 4 + 256)))
     tmpl = synth.make_template(n, pre, FS)
@@ -450,12 +451,13 @@ def test_full_size_properties():
                  "", ft.ampres, FS, "full-size sample")
 
 
-@pytest.mark.parametrize("n", [25000, 30000, 8192, 4096])
-def test_lds_engine_properties_at_scale(n):
-    """The LDS engine on a large device-generated batch of the reference example's trace
-    length (and a short power of two): bin-for-bin agreement with the independent ROCFFT
-    engine up to near-tie flips, idempotence, linearity, circular-shift equivariance, a
-    sample against the oracle."""
+@pytest.mark.parametrize("n,eng", [(25000, "lds"), (30000, "lds"), (8192, "lds"), (4096, "lds"),
+                                   (25000, "fused")])
+def test_lds_engine_properties_at_scale(n, eng):
+    """The LDS engine (and the FUSED kernel of the 25000-sample traces, k_fused25) on a large
+    device-generated batch of the reference example's trace length (and a short power of two):
+    bin-for-bin agreement with the independent ROCFFT engine up to near-tie flips, idempotence,
+    linearity, circular-shift equivariance, a sample against the oracle."""
     import torch
     from detprocess_amd import OFPlan, synth_traces
     pre, B = n // 2, (1 << 31) // (n * 4) // 2
@@ -465,33 +467,33 @@ def test_lds_engine_properties_at_scale(n):
     sigma = float(np.sqrt(np.median(psd) * FS))
     x, truth = synth_traces(B, n, tmpl, sigma, 30 * ft.ampres, 300 * ft.ampres, 0.5, n // 16, seed=4)
     plans = {}
-    for engine in ("lds", "rocfft"):
+    for engine in (eng, "rocfft"):
         p = OFPlan(n, pre, FS, max_batch=8192, device=0, engine=engine)
         p.set_filter(0, ft)
         p.add_search(0, "delay")
         p.add_search(0, "delay", pre - n // 64, pre + n // 64)
         plans[engine] = p
-    a = plans["lds"].process(x)
+    a = plans[eng].process(x)
     b = plans["rocfft"].process(x)
     for off in (0, 8):
         diff = a[:, off + 7] != b[:, off + 7]
         assert float(diff.float().mean()) < 1e-4
         assert torch.allclose(a[:, off + 2], b[:, off + 2], rtol=1e-4)
         assert torch.allclose(a[~diff, off], b[~diff, off], rtol=1e-4, atol=1e-3 * ft.ampres)
-    assert torch.equal(plans["lds"].process(x), a)
+    assert torch.equal(plans[eng].process(x), a)
     has = truth[:, 0] > 0
     dd = (a[has, 7] - pre - truth[has, 1]).abs()
     assert float((dd <= 2).float().mean()) > 0.999
-    a2 = plans["lds"].process(x[:4096] * 2.0)
+    a2 = plans[eng].process(x[:4096] * 2.0)
     assert torch.equal(a2[:, 7], a[:4096, 7])
     assert torch.allclose(a2[:, 0], 2 * a[:4096, 0], rtol=1e-6)
-    a3 = plans["lds"].process(torch.roll(x[:4096], 100, dims=1))
+    a3 = plans[eng].process(torch.roll(x[:4096], 100, dims=1))
     assert torch.equal(a3[:, 7], (a[:4096, 7] + 100) % n)
     idx = np.random.default_rng(1).choice(B, 24, replace=False)
     sel = torch.as_tensor(idx, device=x.device)
     ref = orc.process_events(orc.OFFilter(tmpl, psd, FS, pre), x[sel].cpu().numpy().astype(np.float64),
                              "unconstrained")
-    check_search(a[sel].cpu().numpy().astype(np.float64), 0, ref, "", ft.ampres, FS, f"lds/{n}")
+    check_search(a[sel].cpu().numpy().astype(np.float64), 0, ref, "", ft.ampres, FS, f"{eng}/{n}")
 
 
 def test_coloured_noise_generator_matches_its_psd():
