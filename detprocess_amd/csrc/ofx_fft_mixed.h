@@ -174,4 +174,38 @@ __device__ __forceinline__ void dft20(cpx (&x)[TOT]) {
     for (int k = 0; k < 20; ++k) x[OFF + k] = t[k];
 }
 
+// ---- 10 points, prime-factor map 2 x 5 (ofx_fused25.hip built for 12500-sample traces)
+//   input  n = (5 n1 + 2 n2) mod 10      output k = (5 k1 + 6 k2) mod 10
+__host__ __device__ constexpr int p10(int a, int b) { return (5 * a + 2 * b) % 10; }
+template <int DIR, int TOT, int OFF, int N2>
+__device__ __forceinline__ void d10_s1(cpx (&x)[TOT]) {
+    if constexpr (N2 < 5) {
+        const cpx a = x[OFF + p10(0, N2)], b = x[OFF + p10(1, N2)];
+        x[OFF + p10(0, N2)] = a + b;
+        x[OFF + p10(1, N2)] = a - b;
+        d10_s1<DIR, TOT, OFF, N2 + 1>(x);
+    }
+}
+template <int DIR, int TOT, int OFF, int K1>
+__device__ __forceinline__ void d10_s2(cpx (&x)[TOT]) {
+    if constexpr (K1 < 2) {
+        r5<DIR>(x[OFF + p10(K1, 0)], x[OFF + p10(K1, 1)], x[OFF + p10(K1, 2)], x[OFF + p10(K1, 3)],
+                x[OFF + p10(K1, 4)]);
+        d10_s2<DIR, TOT, OFF, K1 + 1>(x);
+    }
+}
+template <int DIR, int TOT, int OFF>
+__device__ __forceinline__ void dft10(cpx (&x)[TOT]) {
+#ifdef ABL_NOFFT
+    return;
+#endif
+    d10_s1<DIR, TOT, OFF, 0>(x);
+    d10_s2<DIR, TOT, OFF, 0>(x);
+    cpx t[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) t[k] = x[OFF + p10(k % 2, k % 5)];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) x[OFF + k] = t[k];
+}
+
 }  // namespace ofxfft

@@ -41,24 +41,45 @@ using namespace ofxfft;
 
 namespace {
 
-constexpr int R1 = 20, R2 = 25, R3 = 25;
+// The file builds for R1 = 20 (25000 samples; comments below quote these numbers) and, included
+// from ofx_fused12.hip with OFX25_R1 = 10, for 12500 samples (M = 6250 = 10 x 25 x 25: 125 working
+// threads in a 128-thread workgroup, five full rounds of 10-point transforms in F1 / I1 and no
+// partial one, four workgroups per CU).
+#ifndef OFX25_R1
+#define OFX25_R1 20
+#endif
+#if OFX25_R1 == 20
+#define OFX25_FN(x) ofx_fused25_##x
+#define k_fused25 k_fused25
+#else
+#define OFX25_FN(x) ofx_fused12_##x
+#define k_fused25 k_fused12
+#endif
+constexpr int R1 = OFX25_R1, R2 = 25, R3 = 25;
+static_assert(R1 == 20 || R1 == 10, "supported first-stage lengths");
 constexpr int GM = R1 * R2 * R3;        // 12500 packed complex points
 constexpr int GN = 2 * GM;              // 25000 samples
 constexpr int GP = R1 * R2;             // 500 blocks of R3 bins
 constexpr int GT = GP / 2;              // 250 working threads
-constexpr int BLK = 256;
+constexpr int BLK = (GT + 63) / 64 * 64;    // 256
 constexpr int NV1 = R2 * R3;            // 625 virtual threads of F1 / I1
-constexpr int T3 = NV1 - 2 * GT;        // 125 threads carry a third one
-constexpr int NV = 3 * R1;              // 60 complex registers
+constexpr int NRF = NV1 / GT;           // 2 full rounds of them per thread ...
+constexpr int T3 = NV1 - NRF * GT;      // ... and 125 threads carry one more (the "third round")
+constexpr bool PART = T3 > 0;
+constexpr int NR1 = NRF + (PART ? 1 : 0);
+constexpr int W3 = (T3 + 63) / 64;      // waves that hold the partial round
+constexpr int NV = NR1 * R1;            // 60 complex registers
+static_assert(NV >= 2 * R3, "register array");
 constexpr int ROWS = 2 * NV1;           // 1250 samples per register row n1
 constexpr int LD1 = 633;                // D1 row stride (= 25 mod 32, >= 625)
 constexpr int HR1 = R1 / 2;             // D1 rows per pass
+static_assert(GT == HR1 * R3 && R1 * R3 == 2 * GT, "the F2 threads of round h read the rows of pass h");
 constexpr int XB_ELEMS = HR1 * LD1;     // 6330 complex >= 250 * 25
-constexpr int NLOW_MAX = 1250;          // low bins 2 X_k kept in LDS
+constexpr int NLOW_MAX = 5 * GP / 2;    // 1250 low bins 2 X_k kept in LDS
 constexpr int VPAD = 256;               // table row length (threads)
 constexpr int T1PAD = 640;              // anchor table row length (virtual threads of F1)
 constexpr int NWAVE = BLK / OFX_WAVE;
-constexpr int WG_PER_CU = 2;
+constexpr int WG_PER_CU = 512 / BLK;    // 2 (256 VGPRs per thread)
 // The third round of I1 / the tail (virtual threads 500..624) sits in the waves from I3W on:
 // 0 = waves 0, 1 as in F1; 2 = waves 2, 3, so that over a whole trace every wave -- every SIMD,
 // which hosts the same wave of both resident workgroups -- carries five rounds of 20-point
@@ -67,7 +88,7 @@ constexpr int WG_PER_CU = 2;
 #define OFX25_I3W 0
 #endif
 constexpr int I3W = OFX25_I3W;
-constexpr int I3T = 64 * I3W;           // first thread of the inverse third round
+constexpr int I3T = PART ? 64 * I3W : 0;    // first thread of the inverse third round
 static_assert(XB_ELEMS >= GT * R3 && XB_ELEMS * 2 >= GM, "exchange buffer");
 
 #ifndef OFX_XPRIO
@@ -304,9 +325,9 @@ __device__ __forceinline__ void t1_apply(cpx (&d)[NV], const T1Anch& an) {
     B[4] = cmul(B[2], B[2]);
     A[1] = lo2(an.q[1]);
     A[2] = hi2(an.q[1]);
-    A[3] = cmul(A[1], A[2]);
+    if constexpr (R1 > 15) A[3] = cmul(A[1], A[2]);
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < R1 / 5; ++a)
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
             const int k1 = 5 * a + b;
@@ -333,12 +354,33 @@ __device__ __forceinline__ float lowchi2_term(int k, int dl, float amp, cpx x2, 
     return w * g * (rr * rr + ri * ri);
 }
 
+template <int DIR, int OFF>
+__device__ __forceinline__ void dft_r1(cpx (&d)[NV]) {
+    if constexpr (R1 == 20) dft20<DIR, NV, OFF>(d);
+    else dft10<DIR, NV, OFF>(d);
+}
+// the full rounds of F1 / I1: first-stage transforms and inter-stage twiddles of rounds H .. NRF-1
+template <int DIR, int H = 0>
+__device__ __forceinline__ void r1_dfts(cpx (&d)[NV]) {
+    if constexpr (H < NRF) {
+        dft_r1<DIR, R1 * H>(d);
+        r1_dfts<DIR, H + 1>(d);
+    }
+}
+template <bool CONJ, int H = 0>
+__device__ __forceinline__ void r1_twiddles(cpx (&d)[NV], const T1Anch (&g)[NRF]) {
+    if constexpr (H < NRF) {
+        t1_apply<CONJ, R1 * H>(d, g[H]);
+        r1_twiddles<CONJ, H + 1>(d, g);
+    }
+}
+
 // ------------------------------------------------------------------ the kernel
 // FEAT bit 0: searches that are not full-range (scan of the LDS lag dump) or interpolate
 // FEAT bit 1: time-domain windows          FEAT bit 2: channel algebra on load
 // MULTI: several filter slots share the forward transform (spectrum parked per workgroup)
 template <int FEAT, bool MULTI>
-__global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
+__global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (threads, waves per SIMD)
     OfxPlanDev pd, OfxSlotDev sd, Tabs25 tabs, const float* __restrict__ traces,
     const uint8_t* __restrict__ valid, long long n_traces, float* __restrict__ out,
     const SlotArg25* __restrict__ slots, int nslots, float2* __restrict__ spec) {
@@ -347,8 +389,8 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
     Lds25& L = *reinterpret_cast<Lds25*>(smem_raw + sizeof(Shared25));
     const int tid = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool w2 = wave < 2;                       // waves holding a third F1 virtual thread
-    const bool w2i = (I3W == 0) ? w2 : !w2;         // ... and a third I1 virtual thread
+    const bool w2 = PART && wave < W3;              // waves holding a third F1 virtual thread
+    const bool w2i = PART && ((I3W == 0) ? w2 : !w2);   // ... and a third I1 virtual thread
     const int pre = pd.pre;
     const __amdgpu_buffer_rsrc_t t1q = make_rsrc(tabs.t1, 2 * T1PAD * 16);
     const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, VPAD * 8);
@@ -366,19 +408,21 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
     // spills); only the sums of the reductions mask them.
     auto load_rows = [&](const __amdgpu_buffer_rsrc_t rz, int tl) __attribute__((always_inline)) {
         const int tcl = min(tl, GT - 1);
-        const int v3l = min(tl + 2 * GT, NV1 - 1);
+        const int v3l = min(tl + NRF * GT, NV1 - 1);
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < NRF; ++h)
 #pragma unroll
             for (int n1 = 0; n1 < R1; ++n1)
                 d[R1 * h + n1] = buf_ld2(rz, (tcl + GT * h) * 8, n1 * NV1 * 8);
-        if (w2) {
+        if constexpr (PART) {
+            if (w2) {
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1)
-                d[2 * R1 + n1] = buf_ld2(rz, v3l * 8, n1 * NV1 * 8);
-        } else {       // (defined on every path: otherwise the registers stay live around the loop)
+                for (int n1 = 0; n1 < R1; ++n1)
+                    d[NRF * R1 + n1] = buf_ld2(rz, v3l * 8, n1 * NV1 * 8);
+            } else {   // (defined on every path: otherwise the registers stay live around the loop)
 #pragma unroll
-            for (int n1 = 0; n1 < R1; ++n1) d[2 * R1 + n1] = mk(0.0f, 0.0f);
+                for (int n1 = 0; n1 < R1; ++n1) d[NRF * R1 + n1] = mk(0.0f, 0.0f);
+            }
         }
     };
     auto load_trace = [&](long long bb) __attribute__((always_inline)) {
@@ -393,7 +437,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             int tl = tid;
             asm volatile("" : "+v"(tl));
             const int tcl = min(tl, GT - 1);
-            const int v3l = min(tl + 2 * GT, NV1 - 1);
+            const int v3l = min(tl + NRF * GT, NV1 - 1);
             const float* e = traces + (size_t)bb * ev_stride;
             const float w0 = pd.weight[0];
 #pragma unroll
@@ -402,7 +446,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                 const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + (size_t)pd.chan[c] * GN, GN * 4);
                 const float wgt = pd.weight[c];
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NRF; ++h)
 #pragma unroll
                     for (int n1 = 0; n1 < R1; ++n1) {
                         const cpx s = buf_ld2(rz, (tcl + GT * h) * 8, n1 * NV1 * 8);
@@ -412,7 +456,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 #pragma unroll
                     for (int n1 = 0; n1 < R1; ++n1) {
                         const cpx s = buf_ld2(rz, v3l * 8, n1 * NV1 * 8);
-                        d[2 * R1 + n1] = pfma(mk(wgt, wgt), s, d[2 * R1 + n1]);
+                        d[(NR1 - 1) * R1 + n1] = pfma(mk(wgt, wgt), s, d[(NR1 - 1) * R1 + n1]);
                     }
                 }
             }
@@ -470,7 +514,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         const bool act3 = tl < T3;                 // ... and carries a third F1 virtual thread
         const int tc = min(tl, GT - 1);            // role index (idle lanes mirror lane 249)
 
-        const int vt3 = min(tl + 2 * GT, NV1 - 1);  // third F1 virtual thread (idle: mirror of 624)
+        const int vt3 = min(tl + NRF * GT, NV1 - 1);    // third F1 virtual thread (idle: mirror of 624)
         STAMP(0);
         if (!have) load_trace(b);
         combine_terms(b);
@@ -505,7 +549,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                     if (r0 + ROWS <= lo || r0 >= hi) continue;            // uniform: outside
                     if (lo <= r0 && r0 + ROWS <= hi) {                    // uniform: full row
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
+                        for (int h = 0; h < NRF; ++h) {
                             // (dependent forms only, as in ofx_fused.hip)
                             const cpx v = d[R1 * h + n1];
                             s2a = s2a + v;
@@ -514,7 +558,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                             mn = min3f(mn, v.x, v.y);
                         }
                         if (w2) {
-                            const cpx v = d[2 * R1 + n1];
+                            const cpx v = d[(NR1 - 1) * R1 + n1];
                             s2b = s2b + v;
                             sq2b = pfma(v, v, sq2b);
                             mx = max3f(mx, v.x, v.y);
@@ -522,14 +566,14 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                         }
                     } else {                                              // edge row
 #pragma unroll
-                        for (int h = 0; h < 3; ++h) {
-                            if (h == 2 && !w2) continue;                   // uniform
-                            const int n = r0 + 2 * (h == 2 ? vt3 : tc + GT * h);
+                        for (int h = 0; h < NR1; ++h) {
+                            if (h == NRF && !w2) continue;                 // uniform
+                            const int n = r0 + 2 * (h == NRF ? vt3 : tc + GT * h);
                             const bool in0 = (n >= lo) && (n < hi);
                             const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
                             const cpx v = d[R1 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
-                            if (h == 2) {
+                            if (h == NRF) {
                                 sb = (sb + y0) + y1;
                                 sqb = fmaf(y0, y0, fmaf(y1, y1, sqb));
                             } else {
@@ -584,10 +628,10 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         {
             cpx acc = mk(0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < 2 * R1; ++j) acc += d[j];
+            for (int j = 0; j < NRF * R1; ++j) acc += d[j];
             if (w2) {
 #pragma unroll
-                for (int j = 2 * R1; j < NV; ++j) acc += d[j];
+                for (int j = NRF * R1; j < NV; ++j) acc += d[j];
             }
             if (acc.x + acc.y == 1.2345f) row[0] = acc.x;
             have = false;
@@ -597,17 +641,16 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         STAMP(1);
         // ---------------------------------------------------------------- F1
         {
-            const T1Anch g0 = t1_load(t1q, tc);
-            const T1Anch g1 = t1_load(t1q, tc + GT);
+            T1Anch gf[NRF];
+#pragma unroll
+            for (int h = 0; h < NRF; ++h) gf[h] = t1_load(t1q, tc + GT * h);
             __builtin_amdgcn_sched_barrier(0);
-            dft20<-1, NV, 0>(d);
-            dft20<-1, NV, R1>(d);
-            t1_apply<false, 0>(d, g0);
-            t1_apply<false, R1>(d, g1);
+            r1_dfts<-1>(d);
+            r1_twiddles<false>(d, gf);
             if (w2) {
                 const T1Anch g2 = t1_load(t1q, vt3);
-                dft20<-1, NV, 2 * R1>(d);
-                t1_apply<false, 2 * R1>(d, g2);
+                dft_r1<-1, (NR1 - 1) * R1>(d);
+                t1_apply<false, (NR1 - 1) * R1>(d, g2);
             }
         }
         STAMP(2);
@@ -625,12 +668,12 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         for (int p = 0; p < 2; ++p) {
             __syncthreads();
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NRF; ++h)
 #pragma unroll
                 for (int j = 0; j < HR1; ++j) xc[j * LD1 + tc + GT * h] = d[R1 * h + HR1 * p + j];
             if (w2) {
 #pragma unroll
-                for (int j = 0; j < HR1; ++j) xc[j * LD1 + vt3] = d[2 * R1 + HR1 * p + j];
+                for (int j = 0; j < HR1; ++j) xc[j * LD1 + vt3] = d[(NR1 - 1) * R1 + HR1 * p + j];
             }
             __syncthreads();
 #pragma unroll
@@ -752,10 +795,11 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         dft25<+1, NV, R2>(d);
         STAMP(8);
         {
-            const int vt3b = min(max(tl2 - I3T, 0) + 2 * GT, NV1 - 1);
+            const int vt3b = min(max(tl2 - I3T, 0) + NRF * GT, NV1 - 1);
             // anchors of the stage-1 twiddles: requested ahead of the exchange (L2 latency)
-            const T1Anch g0 = t1_load(t1q, tc2);
-            const T1Anch g1 = t1_load(t1q, tc2 + GT);
+            T1Anch gi[NRF];
+#pragma unroll
+            for (int h = 0; h < NRF; ++h) gi[h] = t1_load(t1q, tc2 + GT * h);
             __builtin_amdgcn_sched_barrier(0);
             // ------------------------------------------------------------ E4
 #if OFX_XPRIO
@@ -768,7 +812,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                 for (int n2 = 0; n2 < R2; ++n2) xc[rb1b + R3 * n2] = d[R2 * p + n2];
                 __syncthreads();
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < NRF; ++h)
 #pragma unroll
                     for (int j = 0; j < HR1; ++j)
                         nd[R1 * h + HR1 * p + j] = xc[j * LD1 + tc2 + GT * h];
@@ -776,36 +820,36 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                 // are read when their turn comes in I1 -- ten values less to hold meanwhile)
                 if (p == 0 && w2i) {
 #pragma unroll
-                    for (int j = 0; j < HR1; ++j) nd[2 * R1 + j] = xc[j * LD1 + vt3b];
+                    for (int j = 0; j < HR1; ++j) nd[(NR1 - 1) * R1 + j] = xc[j * LD1 + vt3b];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 2 * R1; ++j) d[j] = nd[j];
+            for (int j = 0; j < NRF * R1; ++j) d[j] = nd[j];
 #if OFX_XPRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
             STAMP(9);
             // ------------------------------------------------------------ I1
-            t1_apply<true, 0>(d, g0);
-            t1_apply<true, R1>(d, g1);
+            r1_twiddles<true>(d, gi);
             // (the third round's anchors: requested once those of the first two are dead, ahead
             // of the two transforms)
-            T1Anch g2 = g1;       // (defined on every path: an undefined value is carried around the loop)
+            T1Anch g2 = gi[NRF - 1];  // (defined on every path: an undefined value is carried around the loop)
             if (w2i) g2 = t1_load(t1q, vt3b);
             __builtin_amdgcn_sched_barrier(0);
-            dft20<+1, NV, 0>(d);
-            dft20<+1, NV, R1>(d);
-            if (w2i) {
+            r1_dfts<+1>(d);
+            if constexpr (PART) {
+                if (w2i) {
 #pragma unroll
-                for (int j = 0; j < HR1; ++j) {
-                    d[2 * R1 + j] = nd[2 * R1 + j];
-                    d[2 * R1 + HR1 + j] = xc[j * LD1 + vt3b];
+                    for (int j = 0; j < HR1; ++j) {
+                        d[NRF * R1 + j] = nd[NRF * R1 + j];
+                        d[NRF * R1 + HR1 + j] = xc[j * LD1 + vt3b];
+                    }
+                    t1_apply<true, NRF * R1>(d, g2);
+                    dft_r1<+1, NRF * R1>(d);
+                } else {
+#pragma unroll
+                    for (int j = NRF * R1; j < NV; ++j) d[j] = mk(0.0f, 0.0f);
                 }
-                t1_apply<true, 2 * R1>(d, g2);
-                dft20<+1, NV, 2 * R1>(d);
-            } else {
-#pragma unroll
-                for (int j = 2 * R1; j < NV; ++j) d[j] = mk(0.0f, 0.0f);
             }
         }
         // d[20 h + n1] = (A(1250 n1 + 2 vt), A(1250 n1 + 2 vt + 1)),  vt = tid + 250 h (idle lanes:
@@ -830,7 +874,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
         const int lane_t = tt & 63, wave_t = tt >> 6;
         const bool act_t = tt < GT;
         const int tct = min(tt, GT - 1);
-        const int vt3t = min(max(tt - I3T, 0) + 2 * GT, NV1 - 1);
+        const int vt3t = min(max(tt - I3T, 0) + NRF * GT, NV1 - 1);
         const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(SDX.s, NLOW_MAX * 8);
         const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(SDX.g, NLOW_MAX * 4);
         constexpr int GS = 10;                     // registers per group (two groups per round)
@@ -871,8 +915,8 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                 for (int g = 0; g < NG; ++g) {
                     if (__builtin_amdgcn_ballot_w64(gm[g] == wmax) == 0) continue;    // uniform
                     const int h = (GS * g) / R1;
-                    if (h == 2 && !w2i) continue;                                     // zeros
-                    const int base = 2 * (h == 2 ? vt3t : tct + GT * h) + pre;
+                    if (h == NRF && !w2i) continue;                                   // zeros
+                    const int base = 2 * (h == NRF ? vt3t : tct + GT * h) + pre;
 #pragma unroll
                     for (int j = GS * g; j < GS * g + GS; ++j) {
                         const int n1 = j - R1 * h;
@@ -918,9 +962,9 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
             for (int e = 0; e < 2; ++e) {
                 __syncthreads();
 #pragma unroll
-                for (int h = 0; h < 3; ++h) {
-                    if (h == 2 && !w2i) continue;
-                    const int vth = (h == 2) ? vt3t : tct + GT * h;
+                for (int h = 0; h < NR1; ++h) {
+                    if (h == NRF && !w2i) continue;
+                    const int vth = (h == NRF) ? vt3t : tct + GT * h;
 #pragma unroll
                     for (int n1 = 0; n1 < R1; ++n1)
                         SH.xb[NV1 * n1 + vth] = e ? d[R1 * h + n1].y : d[R1 * h + n1].x;
@@ -1005,7 +1049,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
                     const int n1 = n / ROWS;
                     const int vt_n = (n - ROWS * n1) >> 1;
                     const int hh = vt_n / GT;
-                    if (best.idx != 0x7fffffff && tt == vt_n - GT * hh + (hh == 2 ? I3T : 0)) {
+                    if (best.idx != 0x7fffffff && tt == vt_n - GT * hh + (hh == NRF ? I3T : 0)) {
                         const int jn = R1 * hh + n1;
                         cpx v = d[0];
 #pragma unroll
@@ -1084,7 +1128,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU) void k_fused25(
 }  // namespace
 
 // =============================================================== host side
-bool ofx_fused25_supported(int n_samples) { return n_samples == GN; }
+bool OFX25_FN(supported)(int n_samples) { return n_samples == GN; }
 
 static int fused25_tables(ofx_plan* p) {
     if (p->d_tw1) return OFX_OK;
@@ -1119,7 +1163,7 @@ static int fused25_tables(ofx_plan* p) {
 //   [25*256 .. +25*128) midG (g_k', g_p') as float2 [slot J][v]; last entry (W_{M/2}, g_{M/2}, 0).
 // Slot J of thread v pairs bin k = v + 500 J with p = M - k (v = 0: k = 500 J for J <= 12 and
 // 250 + 500 (J - 13) above; k = 0 pairs DC with Nyquist).
-int ofx_fused25_prepare_slot(ofx_plan* p, int slot, const double* wf) {
+int OFX25_FN(prepare_slot)(ofx_plan* p, int slot, const double* wf) {
     int rc = fused25_tables(p);
     if (rc) return rc;
     OfxSlotHost& h = p->slot[slot];
@@ -1233,7 +1277,7 @@ static int launch25_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxS
 #endif
 }
 
-int ofx_fused25_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
+int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
                         float* d_out, hipStream_t st) {
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
@@ -1270,7 +1314,7 @@ int ofx_fused25_process(ofx_plan* p, const float* d_traces, const uint8_t* d_val
                 (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
                 feat |= 1;
             if (sq.nlow > NLOW_MAX) {
-                ofx_set_error("FUSED engine (25000 samples): lowchi2_fcutoff covers %d bins (> %d)",
+                ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", GN,
                               sq.nlow, NLOW_MAX);
                 return OFX_ERR_UNSUPPORTED;
             }
@@ -1286,7 +1330,7 @@ int ofx_fused25_process(ofx_plan* p, const float* d_traces, const uint8_t* d_val
         }
         for (int i = 0; i < pd.n_bands; ++i)
             if (pd.band[i].k_hi > NLOW_MAX) {
-                ofx_set_error("FUSED engine (25000 samples): band [%d,%d) exceeds the %d stashed bins",
+                ofx_set_error("FUSED engine (%d samples): band [%d,%d) exceeds the %d stashed bins", GN,
                               pd.band[i].k_lo, pd.band[i].k_hi, NLOW_MAX);
                 return OFX_ERR_UNSUPPORTED;
             }

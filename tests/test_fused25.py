@@ -1,6 +1,8 @@
 """GPU parity tests of the register-resident kernel for 25000-sample traces (the trace length of
 the reference's example YAML, examples/processing/process_example.yaml:93): k_fused25 through the
-C ABI against the fp64 oracle, and against the LDS engine on the same inputs."""
+C ABI against the fp64 oracle, and against the LDS engine on the same inputs.  Every test also
+runs at 12500 samples (10 ms traces, examples/filterdata/filter_data_generation.ipynb: the same
+source built with a 10-point first stage, k_fused12)."""
 import numpy as np
 import pytest
 
@@ -11,6 +13,14 @@ from util import check_search, check_td
 pytestmark = pytest.mark.gpu
 FS = 1.25e6
 N = 25000
+
+
+@pytest.fixture(autouse=True, params=[25000, 12500])
+def _trace_length(request):
+    global N
+    N = request.param
+    yield
+    N = 25000
 
 
 def _mk(pre=None, engine="fused", max_batch=64):
@@ -51,9 +61,10 @@ def test_every_lag_can_win():
     both components, all three rounds of virtual threads, both ends of the rolled range)."""
     plan, ft, filt, tmpl, psd = _mk()
     sid = plan.add_search(0, "delay")
-    lags = np.unique(np.concatenate([np.arange(-12500, 12500, 311), [-12500, -12499, -1, 0, 1, 12498, 12499],
-                                     1250 * np.arange(-10, 10), 1250 * np.arange(-10, 10) + 1249,
-                                     [498, 499, 500, 501, 998, 999, 1000, 1001, 248, 249, 250, 251]]))
+    H, R = N // 2, N // 1250
+    lags = np.unique(np.concatenate([np.arange(-H, H, 311), [-H, -H + 1, -1, 0, 1, H - 2, H - 1],
+                                     1250 * np.arange(-R // 2, R // 2), 1250 * np.arange(-R // 2, R // 2) + 1249,
+                                     [498, 499, 500, 501, 998, 999, 1000, 1001, 248, 249, 250, 251, 123, 124, 125, 126]]))
     x = np.stack([3e-7 * np.roll(tmpl, int(d)) for d in lags]).astype(np.float32)
     out = _run(plan, x)
     o = plan.search_offset(0, sid)
@@ -95,8 +106,9 @@ def test_interpolate_windows_and_cutoffs():
                  "", ft.ampres, FS, "early window")
 
 
-@pytest.mark.parametrize("pre", [7, 1000, 20001, 24990])
-def test_pretrigger_away_from_the_middle(pre):
+@pytest.mark.parametrize("where", [0, 1, 2, 3])
+def test_pretrigger_away_from_the_middle(where):
+    pre = [7, 1000, (4 * N) // 5 + 1, N - 10][where]
     plan, ft, filt, tmpl, psd = _mk(pre=pre)
     s0 = plan.add_search(0, "nodelay")
     s1 = plan.add_search(0, "delay")
@@ -139,9 +151,9 @@ def test_three_slots_windows_bands_and_channel_algebra():
         ids.append((plan.add_search(s, "nodelay", lowchi2_fcutoff=50000.0),
                     plan.add_search(s, "delay", lowchi2_fcutoff=50000.0),
                     plan.add_search(s, "delay", pre - 500, pre + 500, interpolate=(s == 1))))
-    wins = [(100, 9000), (0, N - 1), (12000, 13763), (1250, 2500)]
+    wins = [(100, (9 * N) // 25), (0, N - 1), (N // 2 - 500, N // 2 + 1263), (1250, 2500)]
     wid = [plan.add_tdwindow(a, b) for a, b in wins]
-    bands = [(1, 20), (400, 700), (1000, 1250)]
+    bands = [(1, 20), (N // 60, N // 36), (N // 25, N // 20)]
     bid = [plan.add_band(a, b) for a, b in bands]
     ev, _, _ = synth.make_traces(2 * 21, tmpls[0], psd, FS, fts[0].ampres, seed=314)
     ev = ev.reshape(21, 2, N).astype(np.float32)

@@ -13,7 +13,7 @@ from detprocess_amd import build_filter, synth
 pytestmark = pytest.mark.gpu
 
 FS = 1.25e6
-ENGINES = [(32768, "fused"), (32768, "rocfft"), (32768, "lds"), (25000, "lds"), (25000, "fused"), (4096, "lds"),
+ENGINES = [(32768, "fused"), (32768, "rocfft"), (32768, "lds"), (25000, "lds"), (25000, "fused"), (12500, "fused"), (4096, "lds"),
            (4096, "rocfft"), (1000, "rocfft")]
 
 
@@ -114,7 +114,7 @@ def test_white_psd_gives_the_matched_filter(n, engine):
     assert np.array_equal(out[:, od + 7].astype(int), lag)
 
 
-@pytest.mark.parametrize("n,engine", [(32768, "fused"), (25000, "lds"), (25000, "fused"), (4096, "rocfft"),
+@pytest.mark.parametrize("n,engine", [(32768, "fused"), (25000, "lds"), (25000, "fused"), (12500, "fused"), (4096, "rocfft"),
                                       (1001, "rocfft")])
 def test_time_domain_closed_forms(n, engine):
     """Ramps: baseline / integral / maximum / minimum on end-exclusive slices

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 from detprocess_amd import OFPlan, build_filter, synth, synth_traces
 
-FS, N = 1.25e6, 25000
+FS, N = 1.25e6, int(os.environ.get('N', 25000))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 pre = N // 2
 tmpl = synth.make_template(N, pre, FS); psd = synth.make_psd(N, FS)
