@@ -51,9 +51,11 @@ namespace {
 #if OFX25_R1 == 20
 #define OFX25_FN(x) ofx_fused25_##x
 #define k_fused25 k_fused25
+#define k_fft25 k_fft25
 #else
 #define OFX25_FN(x) ofx_fused12_##x
 #define k_fused25 k_fused12
+#define k_fft25 k_fft12
 #endif
 constexpr int R1 = OFX25_R1, R2 = 25, R3 = 25;
 static_assert(R1 == 20 || R1 == 10, "supported first-stage lengths");
@@ -1125,6 +1127,192 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
 #endif
 }
 
+
+// ------------------------------------------------------------------ the transform on its own
+// Batched complex transform of rows of GM points, natural order in and out, unnormalised (the
+// interface of ofx_ldsfft_exec, ofx_lds.hip): the register-resident stages of k_fused25 without
+// the middle step and the tail.  It serves the N x M engine and the ROCFFT engine at these
+// trace lengths (their transforms run on the GM packed points of a trace), in place of the
+// LDS-resident transform k_lds_fft.
+//   forward: rows z[m] -> Z[k] = sum_m z[m] exp(-2 pi i m k / GM);  inverse: the + sign.
+template <bool FWD>
+__global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fft25(
+    const float2* __restrict__ t1, const float2* __restrict__ t2tab, const float2* __restrict__ in,
+    float2* __restrict__ out, long long rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Shared25& SH = *reinterpret_cast<Shared25*>(smem_raw);
+    const int tid = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool w2 = PART && wave < W3;
+    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(t1, 2 * T1PAD * 16);
+    for (int i = tid; i < R2 * R3; i += BLK) SH.t2[i] = mk(t2tab[i].x, t2tab[i].y);
+    cpx d[NV], nd[NV];
+    cpx* const xc = reinterpret_cast<cpx*>(SH.xb);
+    auto pass2 = [](int h, int k2) { return k2 < 12 ? 0 : (k2 > 12 ? 1 : h); };
+    for (long long b = (long long)blockIdx.x; b < rows; b += (long long)gridDim.x) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const int tc = min(tl, GT - 1);
+        const int vt3 = min(tl + NRF * GT, NV1 - 1);
+        const int k1l = (tc * 1311) >> 15;
+        const int n3u = tc - 25 * k1l;
+        const int rb1 = k1l * LD1 + n3u;
+        const int rbB = (tc == 0) ? 0 : (GT - tc);
+        const int rowB = (tc == 0) ? GP / 2 : GP - tc;      // partner block of thread v
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)b * GM, GM * 8);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(out + (size_t)b * GM, GM * 8);
+        auto st2 = [&](cpx v, int idx) {
+            u32x2 u;
+            u.x = __float_as_uint(v.x);
+            u.y = __float_as_uint(v.y);
+            __builtin_amdgcn_raw_buffer_store_b64(u, rout, idx * 8, 0, 0);
+        };
+        if constexpr (FWD) {
+#pragma unroll
+            for (int h = 0; h < NRF; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1)
+                    d[R1 * h + n1] = buf_ld2(rin, (tc + GT * h) * 8, n1 * NV1 * 8);
+            if (w2) {
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) d[NRF * R1 + n1] = buf_ld2(rin, vt3 * 8, n1 * NV1 * 8);
+            }
+            {
+                T1Anch gf[NRF];
+#pragma unroll
+                for (int h = 0; h < NRF; ++h) gf[h] = t1_load(t1q, tc + GT * h);
+                r1_dfts<-1>(d);
+                r1_twiddles<false>(d, gf);
+                if (w2) {
+                    const T1Anch g2 = t1_load(t1q, vt3);
+                    dft_r1<-1, (NR1 - 1) * R1>(d);
+                    t1_apply<false, (NR1 - 1) * R1>(d, g2);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                       // E1
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < NRF; ++h)
+#pragma unroll
+                    for (int j = 0; j < HR1; ++j) xc[j * LD1 + tc + GT * h] = d[R1 * h + HR1 * p + j];
+                if (w2) {
+#pragma unroll
+                    for (int j = 0; j < HR1; ++j) xc[j * LD1 + vt3] = d[(NR1 - 1) * R1 + HR1 * p + j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) nd[R2 * p + n2] = xc[rb1 + R3 * n2];
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * R2; ++j) d[j] = nd[j];
+            dft25<-1, NV, 0>(d);                                // F2
+            dft25<-1, NV, R2>(d);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int k2 = 1; k2 < R2; ++k2)
+                    d[R2 * h + k2] = cmul(d[R2 * h + k2], SH.t2[k2 * R3 + n3u]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                       // E2
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k2 = 0; k2 < R2; ++k2)
+                        if (pass2(h, k2) == p)
+                            xc[(k1l + HR1 * h + R1 * k2 - GT * p) * R3 + n3u] = d[R2 * h + k2];
+                __syncthreads();
+                const int rr = (p == 0) ? tc : rbB;
+#pragma unroll
+                for (int j = 0; j < R3; ++j) nd[R3 * p + j] = xc[rr * R3 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * R3; ++j) d[j] = nd[j];
+            dft25<-1, NV, 0>(d);                                // F3: blocks v and 500 - v
+            dft25<-1, NV, R3>(d);
+#pragma unroll
+            for (int j = 0; j < R3; ++j) {                      // Z[k_low + 500 k3], natural order
+                st2(d[j], tc + GP * j);
+                st2(d[R3 + j], rowB + GP * j);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < R3; ++j) {
+                d[j] = buf_ld2(rin, tc * 8, j * GP * 8);
+                d[R3 + j] = buf_ld2(rin, rowB * 8, j * GP * 8);
+            }
+            dft25<+1, NV, 0>(d);                                // I3
+            dft25<+1, NV, R3>(d);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                       // E3
+                __syncthreads();
+                {
+                    const int rr = (p == 0) ? tc : rbB;
+#pragma unroll
+                    for (int j = 0; j < R3; ++j) xc[rr * R3 + j] = d[R3 * p + j];
+                }
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int k2 = 0; k2 < R2; ++k2)
+                        if (pass2(h, k2) == p)
+                            nd[R2 * h + k2] = xc[(k1l + HR1 * h + R1 * k2 - GT * p) * R3 + n3u];
+            }
+#pragma unroll
+            for (int j = 0; j < 2 * R2; ++j) d[j] = nd[j];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)                         // I2
+#pragma unroll
+                for (int k2 = 1; k2 < R2; ++k2)
+                    d[R2 * h + k2] = cmulc(d[R2 * h + k2], SH.t2[k2 * R3 + n3u]);
+            dft25<+1, NV, 0>(d);
+            dft25<+1, NV, R2>(d);
+            T1Anch gi[NRF];
+#pragma unroll
+            for (int h = 0; h < NRF; ++h) gi[h] = t1_load(t1q, tc + GT * h);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {                       // E4
+                __syncthreads();
+#pragma unroll
+                for (int n2 = 0; n2 < R2; ++n2) xc[rb1 + R3 * n2] = d[R2 * p + n2];
+                __syncthreads();
+#pragma unroll
+                for (int h = 0; h < NRF; ++h)
+#pragma unroll
+                    for (int j = 0; j < HR1; ++j) nd[R1 * h + HR1 * p + j] = xc[j * LD1 + tc + GT * h];
+                if (p == 0 && w2) {
+#pragma unroll
+                    for (int j = 0; j < HR1; ++j) nd[(NR1 - 1) * R1 + j] = xc[j * LD1 + vt3];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NRF * R1; ++j) d[j] = nd[j];
+            r1_twiddles<true>(d, gi);                           // I1
+            r1_dfts<+1>(d);
+#pragma unroll
+            for (int h = 0; h < NRF; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) st2(d[R1 * h + n1], NV1 * n1 + tc + GT * h);
+            if constexpr (PART) {
+                if (w2) {
+                    const T1Anch g2 = t1_load(t1q, vt3);
+#pragma unroll
+                    for (int j = 0; j < HR1; ++j) {
+                        d[NRF * R1 + j] = nd[NRF * R1 + j];
+                        d[NRF * R1 + HR1 + j] = xc[j * LD1 + vt3];
+                    }
+                    t1_apply<true, NRF * R1>(d, g2);
+                    dft_r1<+1, NRF * R1>(d);
+#pragma unroll
+                    for (int n1 = 0; n1 < R1; ++n1) st2(d[NRF * R1 + n1], NV1 * n1 + vt3);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // =============================================================== host side
@@ -1363,4 +1551,49 @@ int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     memset(&sd0, 0, sizeof(sd0));
     return launch25_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,
                                reinterpret_cast<const SlotArg25*>(p->d_fused_slots), nslots);
+}
+
+// ---- the transform on its own (ofx_ldsfft_* dispatch to these for GM-point rows)
+struct RegFft25 {
+    float2* d_t1 = nullptr;
+    float2* d_t2 = nullptr;
+    int cu_count = 256;
+};
+int OFX25_FN(fft_create)(int n_complex, int device, void** out) {
+    if (n_complex != GM) return OFX_ERR_UNSUPPORTED;
+    ofx_plan tmp;                       // only its table pointers are used
+    int rc = fused25_tables(&tmp);
+    if (rc) return rc;
+    RegFft25* f = new RegFft25();
+    f->d_t1 = tmp.d_tw1;
+    f->d_t2 = tmp.d_tw2;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) f->cu_count = prop.multiProcessorCount;
+    *out = f;
+    return OFX_OK;
+}
+void OFX25_FN(fft_destroy)(void* h) {
+    RegFft25* f = static_cast<RegFft25*>(h);
+    if (!f) return;
+    if (f->d_t1) (void)hipFree(f->d_t1);
+    if (f->d_t2) (void)hipFree(f->d_t2);
+    delete f;
+}
+int OFX25_FN(fft_exec)(void* h, bool forward, const float2* in, float2* out, long long rows,
+                       hipStream_t st) {
+    RegFft25* f = static_cast<RegFft25*>(h);
+    if (rows <= 0) return OFX_OK;
+    long long grid = (long long)f->cu_count * WG_PER_CU;
+    if (grid > rows) grid = rows;
+    if (forward) {
+        OFX_LDS_ATTR_ONCE((k_fft25<true>), sizeof(Shared25));
+        hipLaunchKernelGGL((k_fft25<true>), dim3((unsigned)grid), dim3(BLK), sizeof(Shared25), st,
+                           f->d_t1, f->d_t2, in, out, rows);
+    } else {
+        OFX_LDS_ATTR_ONCE((k_fft25<false>), sizeof(Shared25));
+        hipLaunchKernelGGL((k_fft25<false>), dim3((unsigned)grid), dim3(BLK), sizeof(Shared25), st,
+                           f->d_t1, f->d_t2, in, out, rows);
+    }
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
 }

@@ -925,6 +925,10 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
 
 // ------------------------------------------------------------------ standalone batched FFT
 struct OfxLdsFft {
+    // rows of 12500 / 6250 points (25000 / 12500-sample traces) go to the register-resident
+    // transform of ofx_fused25.hip instead (reg: its handle, reg_kind: 25 or 12)
+    void* reg = nullptr;
+    int reg_kind = 0;
     LdsGeom g;
     float2* d_tw = nullptr;
     int* d_pos = nullptr;
@@ -949,6 +953,23 @@ int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, 
 }  // namespace
 
 int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
+    {
+        void* h = nullptr;
+        int kind = 25;
+        int r = ofx_fused25_fft_create(n_complex, device, &h);
+        if (r == OFX_ERR_UNSUPPORTED) {
+            kind = 12;
+            r = ofx_fused12_fft_create(n_complex, device, &h);
+        }
+        if (r == OFX_OK) {
+            OfxLdsFft* f = new OfxLdsFft();
+            f->reg = h;
+            f->reg_kind = kind;
+            *out = f;
+            return OFX_OK;
+        }
+        if (r != OFX_ERR_UNSUPPORTED) return r;
+    }
     std::vector<int> fac;
     const int M = n_complex;
     bool small = false;
@@ -980,6 +1001,8 @@ int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
 
 void ofx_ldsfft_destroy(OfxLdsFft* f) {
     if (!f) return;
+    if (f->reg_kind == 25) ofx_fused25_fft_destroy(f->reg);
+    if (f->reg_kind == 12) ofx_fused12_fft_destroy(f->reg);
     if (f->d_tw) (void)hipFree(f->d_tw);
     if (f->d_pos) (void)hipFree(f->d_pos);
     delete f;
@@ -988,6 +1011,8 @@ void ofx_ldsfft_destroy(OfxLdsFft* f) {
 int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
                     hipStream_t st) {
     if (rows <= 0) return OFX_OK;
+    if (f->reg_kind == 25) return ofx_fused25_fft_exec(f->reg, forward, in, out, rows, st);
+    if (f->reg_kind == 12) return ofx_fused12_fft_exec(f->reg, forward, in, out, rows, st);
     const bool big = f->g.M >= 1024;
     int max_r = 2;
     for (int i = 0; i < f->g.nfac; ++i) max_r = std::max(max_r, f->g.fac[i]);
