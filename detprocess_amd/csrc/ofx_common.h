@@ -120,7 +120,10 @@ struct OfxFftPlans {
 // ofx_lds.hip: the LDS-resident mixed-radix transform on its own (batched, natural-order rows;
 // lengths 2^a 3^b 5^c that fit in LDS).  create returns OFX_ERR_UNSUPPORTED for other lengths.
 struct OfxLdsFft;
-int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out);
+// allow_reg: rows of 12500 / 6250 points may go to the register-resident transform of
+// ofx_fused25.hip (the N x M engine); the ROCFFT engine, which the tests use as the independent
+// cross-check of the fused kernels, keeps the LDS transform
+int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out, bool allow_reg = false);
 void ofx_ldsfft_destroy(OfxLdsFft* f);
 int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
                     hipStream_t st);
@@ -209,6 +212,10 @@ bool ofx_fused25_supported(int n_samples);
 int ofx_fused25_prepare_slot(ofx_plan* p, int slot, const double* wf);
 int ofx_fused25_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                         long long n, float* d_out, hipStream_t st);
+int ofx_fused_fft_create(int n_complex, int device, void** h);        // rows of 16384 complex points
+void ofx_fused_fft_destroy(void* h);
+int ofx_fused_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,
+                       hipStream_t st);
 int ofx_fused25_fft_create(int n_complex, int device, void** h);      // rows of 12500 complex points
 void ofx_fused25_fft_destroy(void* h);
 int ofx_fused25_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,

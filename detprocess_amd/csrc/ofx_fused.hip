@@ -1342,6 +1342,130 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
 #endif
 }
 
+
+// ------------------------------------------------------------------ the transform on its own
+// Batched complex transform of rows of FM = 16384 points, natural order in and out, unnormalised:
+// the register-resident stages of k_fused (F1 E1 F2 E2 F3, or I3 E3 I2 E4 I1) without the middle
+// step and the tail.  The N x M engine runs its transforms of 32768-sample traces on it instead
+// of rocFFT (ofx_nxm.hip; the ROCFFT engine keeps rocFFT: the tests use it as the independent
+// cross-check of k_fused).
+template <bool FWD>
+__global__ __launch_bounds__(FT, WG_PER_CU) void k_fft32(const float2* __restrict__ t1,
+                                                         const float2* __restrict__ t2tab,
+                                                         const float2* __restrict__ in,
+                                                         float2* __restrict__ out, long long rows) {
+    static_assert(VT == 2 && SPLIT_EXCHANGE && !PP, "product layout");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    FusedShared& SH = *reinterpret_cast<FusedShared*>(smem_raw);
+    const int tid = (int)threadIdx.x;
+    const __amdgpu_buffer_rsrc_t t1q = make_rsrc(t1, 5 * 512 * 16);
+    for (int i = tid; i < 512; i += FT) SH.t2[i] = mk(t2tab[i].x, t2tab[i].y);
+    cpx d[NV];
+    auto exchange = [&](auto widx, auto wpass, auto ridx, auto rpass, int hb) {
+        cpx* xc = reinterpret_cast<cpx*>(SH.xb);
+        cpx nd[NV];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (wpass(h, j) == p) xc[widx(h, j) - p * hb] = d[32 * h + j];
+            __syncthreads();
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (rpass(h, j) == p) nd[32 * h + j] = xc[ridx(h, j) - p * hb];
+        }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) d[j] = nd[j];
+    };
+    for (long long b = (long long)blockIdx.x; b < rows; b += (long long)gridDim.x) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        const Roles R0(tl), R1(tl + FT);
+        auto RR = [&](int h) -> const Roles& { return h == 0 ? R0 : R1; };
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(in + (size_t)b * FM, FM * 8);
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(out + (size_t)b * FM, FM * 8);
+        auto st2 = [&](cpx v, int idx) {
+            u32x2 u;
+            u.x = __float_as_uint(v.x);
+            u.y = __float_as_uint(v.y);
+            __builtin_amdgcn_raw_buffer_store_b64(u, rout, idx * 8, 0, 0);
+        };
+        if constexpr (FWD) {
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1)
+                    d[32 * h + n1] = buf_ld2(rin, (tl + FT * h) * 8, n1 * 4096);
+            const T1Anch g0 = t1_load(t1q, tl);
+            const T1Anch g1 = t1_load(t1q, tl + FT);
+            dft<32, -1, NV, 0>(d);
+            dft<32, -1, NV, 32>(d);
+            t1_apply<false, 0>(d, g0);
+            t1_apply<false, 32>(d, g1);
+            exchange([&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; },
+                     [&](int h, int j) { return RR(h).e1r(j); }, [](int h, int) { return h; }, HB1);
+            dft<32, -1, NV, 0>(d);
+            dft<32, -1, NV, 32>(d);
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int k2 = 1; k2 < 32; ++k2)
+                    d[32 * h + k2] = cmul(d[32 * h + k2], SH.t2[k2 * 16 + RR(h).n3u]);
+            exchange([&](int h, int j) { return RR(h).e2w(j); }, [](int, int j) { return j >> 4; },
+                     [&](int h, int j) { return RR(h).e2r(j); }, [](int, int j) { return j >> 4; }, HB2);
+            dft<16, -1, NV, 0>(d);
+            dft<16, -1, NV, 16>(d);
+            dft<16, -1, NV, 32>(d);
+            dft<16, -1, NV, 48>(d);
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {          // Z[k_low + 1024 k3]: blocks v and its partner
+                    st2(d[32 * h + j], RR(h).vt + 1024 * j);
+                    st2(d[32 * h + 16 + j], RR(h).kB + 1024 * j);
+                }
+        } else {
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    d[32 * h + j] = buf_ld2(rin, RR(h).vt * 8, j * 8192);
+                    d[32 * h + 16 + j] = buf_ld2(rin, RR(h).kB * 8, j * 8192);
+                }
+            dft<16, +1, NV, 0>(d);
+            dft<16, +1, NV, 16>(d);
+            dft<16, +1, NV, 32>(d);
+            dft<16, +1, NV, 48>(d);
+            exchange([&](int h, int j) { return RR(h).e2r(j); }, [](int, int j) { return j >> 4; },
+                     [&](int h, int j) { return RR(h).e2w(j); }, [](int, int j) { return j >> 4; }, HB2);
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int k2 = 1; k2 < 32; ++k2)
+                    d[32 * h + k2] = cmulc(d[32 * h + k2], SH.t2[k2 * 16 + RR(h).n3u]);
+            dft<32, +1, NV, 0>(d);
+            dft<32, +1, NV, 32>(d);
+            const T1Anch g0 = t1_load(t1q, tl);
+            const T1Anch g1 = t1_load(t1q, tl + FT);
+            exchange([&](int h, int j) { return RR(h).e1r(j); }, [](int h, int) { return h; },
+                     [&](int h, int j) { return RR(h).e1w(j); }, [](int, int j) { return j >> 4; }, HB1);
+            t1_apply<true, 0>(d, g0);
+            t1_apply<true, 32>(d, g1);
+            dft<32, +1, NV, 0>(d);
+            dft<32, +1, NV, 32>(d);
+#pragma unroll
+            for (int h = 0; h < VT; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) st2(d[32 * h + n1], 512 * n1 + tl + FT * h);
+        }
+    }
+}
+
 }  // namespace
 
 // =============================================================== host side
@@ -1632,4 +1756,49 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     return launch_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,
                              reinterpret_cast<const FusedSlotArg*>(p->d_fused_slots), nslots,
                              nstash);
+}
+
+// ---- the transform on its own (rows of 16384 complex points; used by the N x M engine)
+struct RegFft32 {
+    float2* d_t1 = nullptr;
+    float2* d_t2 = nullptr;
+    int cu_count = 256;
+};
+int ofx_fused_fft_create(int n_complex, int device, void** out) {
+    if (n_complex != FM || VT != 2 || PP) return OFX_ERR_UNSUPPORTED;
+    ofx_plan tmp;                       // only its table pointers are used
+    int rc = fused_tables(&tmp);
+    if (rc) return rc;
+    RegFft32* f = new RegFft32();
+    f->d_t1 = tmp.d_tw1;
+    f->d_t2 = tmp.d_tw2;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) f->cu_count = prop.multiProcessorCount;
+    *out = f;
+    return OFX_OK;
+}
+void ofx_fused_fft_destroy(void* h) {
+    RegFft32* f = static_cast<RegFft32*>(h);
+    if (!f) return;
+    if (f->d_t1) (void)hipFree(f->d_t1);
+    if (f->d_t2) (void)hipFree(f->d_t2);
+    delete f;
+}
+int ofx_fused_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,
+                       hipStream_t st) {
+    RegFft32* f = static_cast<RegFft32*>(h);
+    if (rows <= 0) return OFX_OK;
+    long long grid = (long long)f->cu_count * WG_PER_CU;
+    if (grid > rows) grid = rows;
+    if (forward) {
+        OFX_LDS_ATTR_ONCE((k_fft32<true>), sizeof(FusedShared));
+        hipLaunchKernelGGL((k_fft32<true>), dim3((unsigned)grid), dim3(FT), sizeof(FusedShared), st,
+                           f->d_t1, f->d_t2, in, out, rows);
+    } else {
+        OFX_LDS_ATTR_ONCE((k_fft32<false>), sizeof(FusedShared));
+        hipLaunchKernelGGL((k_fft32<false>), dim3((unsigned)grid), dim3(FT), sizeof(FusedShared), st,
+                           f->d_t1, f->d_t2, in, out, rows);
+    }
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
 }

@@ -925,8 +925,9 @@ int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, 
 
 // ------------------------------------------------------------------ standalone batched FFT
 struct OfxLdsFft {
-    // rows of 12500 / 6250 points (25000 / 12500-sample traces) go to the register-resident
-    // transform of ofx_fused25.hip instead (reg: its handle, reg_kind: 25 or 12)
+    // rows of 16384 / 12500 / 6250 points (32768 / 25000 / 12500-sample traces) go to the
+    // register-resident transforms of ofx_fused.hip / ofx_fused25.hip instead (reg: the handle,
+    // reg_kind: 32, 25 or 12)
     void* reg = nullptr;
     int reg_kind = 0;
     LdsGeom g;
@@ -952,11 +953,15 @@ int launch_lds_fft(OfxLdsFft* f, const float2* in, float2* out, long long rows, 
 }
 }  // namespace
 
-int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
-    {
+int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out, bool allow_reg) {
+    if (allow_reg) {
         void* h = nullptr;
-        int kind = 25;
-        int r = ofx_fused25_fft_create(n_complex, device, &h);
+        int kind = 32;
+        int r = ofx_fused_fft_create(n_complex, device, &h);
+        if (r == OFX_ERR_UNSUPPORTED) {
+            kind = 25;
+            r = ofx_fused25_fft_create(n_complex, device, &h);
+        }
         if (r == OFX_ERR_UNSUPPORTED) {
             kind = 12;
             r = ofx_fused12_fft_create(n_complex, device, &h);
@@ -1001,6 +1006,7 @@ int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out) {
 
 void ofx_ldsfft_destroy(OfxLdsFft* f) {
     if (!f) return;
+    if (f->reg_kind == 32) ofx_fused_fft_destroy(f->reg);
     if (f->reg_kind == 25) ofx_fused25_fft_destroy(f->reg);
     if (f->reg_kind == 12) ofx_fused12_fft_destroy(f->reg);
     if (f->d_tw) (void)hipFree(f->d_tw);
@@ -1011,6 +1017,7 @@ void ofx_ldsfft_destroy(OfxLdsFft* f) {
 int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, long long rows,
                     hipStream_t st) {
     if (rows <= 0) return OFX_OK;
+    if (f->reg_kind == 32) return ofx_fused_fft_exec(f->reg, forward, in, out, rows, st);
     if (f->reg_kind == 25) return ofx_fused25_fft_exec(f->reg, forward, in, out, rows, st);
     if (f->reg_kind == 12) return ofx_fused12_fft_exec(f->reg, forward, in, out, rows, st);
     const bool big = f->g.M >= 1024;

@@ -416,8 +416,8 @@ int process_device(ofx_nxm* p, const float* traces, const uint8_t* valid, long l
     if (!p->ldsfft_tried) {
         p->ldsfft_tried = true;
         const int Mh = N / 2;
-        if ((Mh & (Mh - 1)) != 0) {
-            const int r = ofx_ldsfft_create(Mh, p->device, &p->ldsfft);
+        if ((Mh & (Mh - 1)) != 0 || Mh == 16384) {     // 16384: the register-resident transform
+            const int r = ofx_ldsfft_create(Mh, p->device, &p->ldsfft, true);
             if (r != OFX_OK && r != OFX_ERR_UNSUPPORTED) return r;
         }
     }
