@@ -156,6 +156,7 @@ struct Tabs25 {
     const float2* midG;   // [25][256]  (g_k', g_p')
     const float2* tbase;  // [256]      T_v = i exp(-2 pi i v / N); T of slot J is T_v w_50^J
     float2 tb0hi;         // base of thread 0 for its slots J >= 13 (block 250)
+    unsigned rowmask;     // register rows n1 (1250 lags each) the slot's windowed searches touch
     float2 wq;            // W_{M/2}
     float gq;             // g_{M/2}
 };
@@ -178,16 +179,13 @@ __device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int s
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float min3f(float a, float b, float c) {
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// (plain fmaxf / fminf: the compiler forms v_max3_f32 / v_min3_f32 itself.  The inline-asm forms of
+// ofx_fused.hip gave wrong SEARCH results in the <2, true> and <6, true> instantiations of this
+// kernel -- time-domain windows and several slots, no windowed fit: chi2_0 off by 1e-3, found by
+// tools/fuzz_engines.py -- and exact ones with these; tests/test_fused25.py sweeps every
+// instantiation against the oracle since.)
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }
 __device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
 __device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
 __device__ __forceinline__ cpx cconj(cpx z) { return z * mk(1.0f, -1.0f); }
@@ -559,20 +557,23 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                             mx = max3f(mx, v.x, v.y);
                             mn = min3f(mn, v.x, v.y);
                         }
-                        if (w2) {
-                            const cpx v = d[(NR1 - 1) * R1 + n1];
+                        if constexpr (PART) {
+                            // (every wave: the waves without a third round hold zeros there and are
+                            // masked by `act3`; a wave-uniform branch around these lines made the
+                            // <2, true> / <6, true> instantiations compute wrong SEARCH results)
+                            const cpx v = d[NRF * R1 + n1];
                             s2b = s2b + v;
                             sq2b = pfma(v, v, sq2b);
-                            mx = max3f(mx, v.x, v.y);
-                            mn = min3f(mn, v.x, v.y);
+                            mx = max3f(mx, act3 ? v.x : -INFINITY, act3 ? v.y : -INFINITY);
+                            mn = min3f(mn, act3 ? v.x : INFINITY, act3 ? v.y : INFINITY);
                         }
                     } else {                                              // edge row
 #pragma unroll
                         for (int h = 0; h < NR1; ++h) {
-                            if (h == NRF && !w2) continue;                 // uniform
                             const int n = r0 + 2 * (h == NRF ? vt3 : tc + GT * h);
-                            const bool in0 = (n >= lo) && (n < hi);
-                            const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                            const bool on = (h == NRF) ? act3 : true;      // (mirrors: max / min unharmed)
+                            const bool in0 = on && (n >= lo) && (n < hi);
+                            const bool in1 = on && (n + 1 >= lo) && (n + 1 < hi);
                             const cpx v = d[R1 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
                             if (h == NRF) {
@@ -961,6 +962,51 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
         // windowed / outside-window fits scan the lag dump: even lags, then odd lags
         if constexpr (FEAT & 1) {
             if (lane_t < OFX_MAX_SEARCHES) L.wc[lane_t][wave_t] = ofx_cand_none();
+            // Narrow windows (the usual case: +-100 us is 250 lags, one or two of the R1 register rows
+            // of 1250 lags): only the rows the windowed searches touch are dumped, complex, in ONE
+            // pass (row n1 -> slot popcount(rowmask below n1); up to NSLOT rows fit the buffer).
+            const unsigned rmask = TBX.rowmask;
+            constexpr int NSLOT = (2 * XB_ELEMS) / ROWS;
+            if (__builtin_popcount(rmask) <= NSLOT) {
+                __syncthreads();
+                int slotb = 0;                                   // uniform: slot * 625
+#pragma unroll
+                for (int n1 = 0; n1 < R1; ++n1) {
+                    if (!((rmask >> n1) & 1u)) continue;         // uniform
+#pragma unroll
+                    for (int h = 0; h < NR1; ++h) {
+                        if (h == NRF && !w2i) continue;
+                        const int vth = (h == NRF) ? vt3t : tct + GT * h;
+                        xc[slotb + vth] = d[R1 * h + n1];
+                    }
+                    slotb += NV1;
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int q = 0; q < SDX.n_search; ++q) {
+                    const OfxSearchDev& sq = SDX.search[q];
+                    const bool full = !sq.outside && sq.lo == 0 && sq.hi == GN;
+                    if (sq.kind != OFX_SEARCH_DELAY || full) continue;
+                    OfxCand c = ofx_cand_none();
+                    auto scan = [&](int i0, int i1) {
+                        for (int i = i0 + tt; i < i1; i += BLK) {
+                            int n = i - pre;
+                            n = n < 0 ? n + GN : n;
+                            const int n1 = n / ROWS;
+                            const int sl = __builtin_popcount(rmask & ((1u << n1) - 1u));
+                            ofx_cand_take(c, SH.xb[sl * ROWS + (n - ROWS * n1)], i);
+                        }
+                    };
+                    if (sq.outside) {
+                        scan(0, sq.lo);
+                        scan(sq.hi, GN);
+                    } else {
+                        scan(sq.lo, sq.hi);
+                    }
+                    c = ofx_cand_wave_reduce(c);
+                    if (lane_t == 0) L.wc[q][wave_t] = c;
+                }
+            } else
             for (int e = 0; e < 2; ++e) {
                 __syncthreads();
 #pragma unroll
@@ -1501,6 +1547,29 @@ int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             if (sq.kind == OFX_SEARCH_DELAY &&
                 (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
                 feat |= 1;
+            if (sq.kind == OFX_SEARCH_DELAY && !(sq.lo == 0 && sq.hi == p->N && !sq.outside)) {
+                // rows of lags n = (i - pre) mod N for the rolled indices i the search visits
+                auto mark = [&](int i0, int i1) {
+                    for (int i = i0; i < i1;) {
+                        int nl = i - p->pre;
+                        if (nl < 0) nl += GN;
+                        a.tabs.rowmask |= 1u << (nl / ROWS);
+                        const int row_end = (nl / ROWS + 1) * ROWS;           // first lag of the next row
+                        i += std::max(1, row_end - nl);
+                    }
+                    if (i1 > i0) {
+                        int nl = i1 - 1 - p->pre;
+                        if (nl < 0) nl += GN;
+                        a.tabs.rowmask |= 1u << (nl / ROWS);
+                    }
+                };
+                if (sq.outside) {
+                    mark(0, sq.lo);
+                    mark(sq.hi, GN);
+                } else {
+                    mark(sq.lo, sq.hi);
+                }
+            }
             if (sq.nlow > NLOW_MAX) {
                 ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", GN,
                               sq.nlow, NLOW_MAX);

@@ -261,3 +261,56 @@ def test_agrees_with_the_lds_engine_at_scale():
     assert np.all(np.abs(a[keep, 0] - b[keep, 0]) <= 2e-5 * np.abs(b[keep, 0]) + 2e-4 * ft.ampres)
     assert np.all(np.abs(a[keep, 2] - b[keep, 2]) <= 2e-5 * np.abs(b[keep, 2]) + 4e-6 * b[keep, 4])
     assert np.allclose(a[:, 4], b[:, 4], rtol=1e-5)
+
+
+@pytest.mark.parametrize("feat", range(8))
+@pytest.mark.parametrize("nslots", [1, 2, 3])
+def test_every_kernel_instantiation_vs_oracle(feat, nslots):
+    """One plan per instantiation of the kernel -- FEAT bit 0 a windowed fit, bit 1 time-domain
+    windows, bit 2 channel algebra, one / several filter slots -- with every search of every slot
+    and every window checked against the oracle on every event (the fuzz found an instantiation,
+    windows + several slots without a windowed fit, that no other test built)."""
+    import torch
+    from detprocess_amd import OFPlan
+    pre, B = N // 2 + 37, 48
+    kinds = ("pulse", "glitch", "muon")[:nslots]
+    psd = synth.make_psd(N, FS)
+    tmpls = [synth.make_template(N, pre, FS, k) for k in kinds]
+    fts = [build_filter(t, psd, FS, pre) for t in tmpls]
+    filts = [orc.OFFilter(t, psd, FS, pre) for t in tmpls]
+    plan = OFPlan(N, pre, FS, max_batch=64, device=0, engine="fused")
+    ids = []
+    for s, ft in enumerate(fts):
+        plan.set_filter(s, ft)
+        ss = [("nodelay", plan.add_search(s, "nodelay")), ("unconstrained", plan.add_search(s, "delay"))]
+        if feat & 1:
+            ss.append(("constrained", plan.add_search(s, "delay", pre - 400, pre + 400)))
+        ids.append(ss)
+    wins = [(N // 10, N // 2), (N // 2 - 300, N // 2 + 900)] if feat & 2 else []
+    wid = [plan.add_tdwindow(a, b) for a, b in wins]
+    nch = 2 if feat & 4 else 1
+    ev, _, _ = synth.make_traces(B * nch, tmpls[0], psd, FS, fts[0].ampres, seed=5 + feat, max_delay=N // 16)
+    ev = ev.reshape(B, nch, N).astype(np.float32)
+    if feat & 4:
+        plan.set_channels(2, [1, 0], [1.0, -0.5])
+        x64 = ev[:, 1].astype(np.float64) - 0.5 * ev[:, 0].astype(np.float64)
+        out = plan.process(torch.as_tensor(ev, device="cuda:0")).cpu().numpy().astype(np.float64)
+    else:
+        x64 = ev[:, 0].astype(np.float64)
+        out = plan.process(torch.as_tensor(ev[:, 0], device="cuda:0")).cpu().numpy().astype(np.float64)
+    for s, (ft, filt) in enumerate(zip(fts, filts)):
+        for mode, sid in ids[s]:
+            kw = dict(window_min_index=pre - 400, window_max_index=pre + 400) if mode == "constrained" else {}
+            r = orc.process_events(filt, x64, mode, **kw)
+            o = plan.search_offset(s, sid)
+            assert np.array_equal(out[:, o + 7].astype(int), r["index"]), (feat, nslots, s, mode)
+            tol = 3e-5 if feat & 4 else 1e-5          # (the combined trace is rounded to fp32 on the device)
+            assert np.all(np.abs(out[:, o] - r["amp"]) <= tol * np.abs(r["amp"]) + 2e-4 * ft.ampres), (feat, nslots, s, mode)
+            assert np.all(np.abs(out[:, o + 2] - r["chi2"]) <= tol * r["chi2"] + 4e-6 * out[:, o + 4]), (feat, nslots, s, mode)
+            assert np.all(np.abs(out[:, o + 3] - r["lowchi2"]) <= tol * r["lowchi2"] + 4e-6 * out[:, o + 4]), (feat, nslots, s, mode)
+    sc = np.abs(x64).max()
+    for (a, b), w in zip(wins, wid):
+        t_ = plan.tdwindow_offset(w)
+        assert np.allclose(out[:, t_ + 0], orc.baseline(x64, a, b), rtol=1e-4, atol=1e-6 * sc)
+        assert np.allclose(out[:, t_ + 2], x64[:, a:b].max(axis=1), rtol=2e-6, atol=1e-7 * sc)
+        assert np.allclose(out[:, t_ + 3], x64[:, a:b].min(axis=1), rtol=2e-6, atol=1e-7 * sc)

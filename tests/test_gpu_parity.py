@@ -634,3 +634,59 @@ def test_rejected_filter_table_leaves_the_plan_as_it_was():
     plan.set_filter(1, ft)              # and a good table afterwards takes effect
     after = _run(plan, x32)
     assert np.array_equal(after[:, 8:16], before[:, 0:8]) and np.array_equal(after[:, 0:8], before[:, 0:8])
+
+
+@pytest.mark.parametrize("feat", range(16))
+@pytest.mark.parametrize("nslots", [1, 2])
+def test_every_instantiation_of_the_fused_kernel_vs_oracle(feat, nslots):
+    """One plan per instantiation of k_fused -- FEAT bit 0 a windowed fit, bit 1 time-domain windows,
+    bit 2 channel algebra, bit 3 a low-frequency cut-off beyond the LDS stash, one / several slots --
+    with every search and window checked against the oracle on every event."""
+    import torch
+    from detprocess_amd import OFPlan
+    n, B = 32768, 24
+    pre = n // 2 - 211
+    kinds = ("pulse", "glitch")[:nslots]
+    psd = synth.make_psd(n, FS)
+    tmpls = [synth.make_template(n, pre, FS, k) for k in kinds]
+    fts = [build_filter(t, psd, FS, pre) for t in tmpls]
+    filts = [orc.OFFilter(t, psd, FS, pre) for t in tmpls]
+    plan = OFPlan(n, pre, FS, max_batch=64, device=0, engine="fused")
+    fc = 50000.0 if feat & 8 else 10000.0
+    ids = []
+    for s, ft in enumerate(fts):
+        plan.set_filter(s, ft)
+        ss = [("nodelay", plan.add_search(s, "nodelay", lowchi2_fcutoff=fc)),
+              ("unconstrained", plan.add_search(s, "delay", lowchi2_fcutoff=fc))]
+        if feat & 1:
+            ss.append(("constrained", plan.add_search(s, "delay", pre - 400, pre + 400, lowchi2_fcutoff=fc)))
+        ids.append(ss)
+    wins = [(n // 10, n // 2), (n // 2 - 300, n // 2 + 900)] if feat & 2 else []
+    wid = [plan.add_tdwindow(a, b) for a, b in wins]
+    nch = 2 if feat & 4 else 1
+    ev, _, _ = synth.make_traces(B * nch, tmpls[0], psd, FS, fts[0].ampres, seed=50 + feat, max_delay=n // 16)
+    ev = ev.reshape(B, nch, n).astype(np.float32)
+    if feat & 4:
+        plan.set_channels(2, [1, 0], [1.0, -0.5])
+        x64 = ev[:, 1].astype(np.float64) - 0.5 * ev[:, 0].astype(np.float64)
+        out = plan.process(torch.as_tensor(ev, device="cuda:0")).cpu().numpy().astype(np.float64)
+    else:
+        x64 = ev[:, 0].astype(np.float64)
+        out = plan.process(torch.as_tensor(ev[:, 0], device="cuda:0")).cpu().numpy().astype(np.float64)
+    assert plan.engine == "fused"
+    tol = 3e-5 if feat & 4 else 1e-5                  # (the combined trace is rounded to fp32 on the device)
+    for s, (ft, filt) in enumerate(zip(fts, filts)):
+        for mode, sid in ids[s]:
+            kw = dict(window_min_index=pre - 400, window_max_index=pre + 400) if mode == "constrained" else {}
+            r = orc.process_events(filt, x64, mode, lowchi2_fcutoff=fc, **kw)
+            o = plan.search_offset(s, sid)
+            assert np.array_equal(out[:, o + 7].astype(int), r["index"]), (feat, nslots, s, mode)
+            assert np.all(np.abs(out[:, o] - r["amp"]) <= tol * np.abs(r["amp"]) + 2e-4 * ft.ampres), (feat, nslots, s, mode)
+            assert np.all(np.abs(out[:, o + 2] - r["chi2"]) <= tol * r["chi2"] + 4e-6 * out[:, o + 4]), (feat, nslots, s, mode)
+            assert np.all(np.abs(out[:, o + 3] - r["lowchi2"]) <= tol * r["lowchi2"] + 4e-6 * out[:, o + 4]), (feat, nslots, s, mode)
+    sc = np.abs(x64).max()
+    for (a, b), w in zip(wins, wid):
+        t_ = plan.tdwindow_offset(w)
+        assert np.allclose(out[:, t_ + 0], orc.baseline(x64, a, b), rtol=1e-4, atol=1e-6 * sc)
+        assert np.allclose(out[:, t_ + 2], x64[:, a:b].max(axis=1), rtol=2e-6, atol=1e-7 * sc)
+        assert np.allclose(out[:, t_ + 3], x64[:, a:b].min(axis=1), rtol=2e-6, atol=1e-7 * sc)

@@ -283,6 +283,8 @@ def run_fused(cases, seed, verbose=True, n=32768):
         # beyond 512 bins: the stash (32768 samples); 25000 samples: up to the 1250 bins kept in LDS
         fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, 120000.0 if n == 32768 else 62000.0]))
         tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)} fcut={fcut_c}'
+        if verbose:
+            print('   searches', searches, 'windows', tdw, flush=True)
         outs = {}
         try:
             for eng in ('fused', 'rocfft'):
@@ -310,6 +312,13 @@ def run_fused(cases, seed, verbose=True, n=32768):
                     o = offs[s][q]
                     flips = a[ok, o + 7] != b[ok, o + 7]
                     # a flipped bin must be a near tie: both engines see the same chi2 there
+                    if flips.sum() > max(1, 0.01 * flips.size):
+                        ev_ = np.nonzero(ok)[0][flips][:10]
+                        print('   flipped events', [(int(e_), int(a[e_, o + 7]), int(b[e_, o + 7]), float(a[e_, o + 2]), float(b[e_, o + 2]),
+                                                      float(a[e_, o]), float(b[e_, o])) for e_ in ev_], flush=True)
+                        ro_ = orc.process_events(filts[s], comb[ev_[:4]], 'nodelay' if k == 'nodelay' else 'constrained', fcut_c,
+                                                 **({} if k == 'nodelay' else dict(window_min_index=lo, window_max_index=hi, lgc_outside_window=outside)))
+                        print('   oracle there: idx', ro_['index'], 'chi2', ro_['chi2'], 'amp', ro_['amp'], flush=True)
                     assert flips.sum() <= max(1, 0.01 * flips.size), tag + f' slot {s} search {q}: {flips.sum()} bin flips'
                     if flips.any():
                         assert np.allclose(a[ok][flips, o + 2], b[ok][flips, o + 2], rtol=1e-5), tag + f' flip is not a tie s{s} q{q}'
