@@ -415,7 +415,10 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
             for (int n1 = 0; n1 < R1; ++n1)
                 d[R1 * h + n1] = buf_ld2(rz, (tcl + GT * h) * 8, n1 * NV1 * 8);
         if constexpr (PART) {
-            if (w2) {
+            // (plans with time-domain windows: the waves without a third round load a copy of
+            // virtual thread 624 -- mirrors, like the idle lanes -- so that the window sums below
+            // need neither a branch nor a mask on these registers)
+            if (w2 || (FEAT & 2)) {
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1)
                     d[NRF * R1 + n1] = buf_ld2(rz, v3l * 8, n1 * NV1 * 8);
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                         const cpx s = buf_ld2(rz, (tcl + GT * h) * 8, n1 * NV1 * 8);
                         d[R1 * h + n1] = pfma(mk(wgt, wgt), s, d[R1 * h + n1]);
                     }
-                if (w2) {
+                if (PART && (w2 || (FEAT & 2))) {
 #pragma unroll
                     for (int n1 = 0; n1 < R1; ++n1) {
                         const cpx s = buf_ld2(rz, v3l * 8, n1 * NV1 * 8);
@@ -558,22 +561,24 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                             mn = min3f(mn, v.x, v.y);
                         }
                         if constexpr (PART) {
-                            // (every wave: the waves without a third round hold zeros there and are
-                            // masked by `act3`; a wave-uniform branch around these lines made the
-                            // <2, true> / <6, true> instantiations compute wrong SEARCH results)
+                            // (every wave, no branch: the waves without a third round hold a copy of
+                            // virtual thread 624 there, see load_rows; sums are masked by `act3` at
+                            // the end, copies cannot change max / min.  A wave-uniform branch around
+                            // these lines made the <2, true> / <6, true> instantiations compute wrong
+                            // SEARCH results -- the same on every run, cause not found;
+                            // tests/test_fused25.py builds every instantiation since.)
                             const cpx v = d[NRF * R1 + n1];
                             s2b = s2b + v;
                             sq2b = pfma(v, v, sq2b);
-                            mx = max3f(mx, act3 ? v.x : -INFINITY, act3 ? v.y : -INFINITY);
-                            mn = min3f(mn, act3 ? v.x : INFINITY, act3 ? v.y : INFINITY);
+                            mx = max3f(mx, v.x, v.y);
+                            mn = min3f(mn, v.x, v.y);
                         }
                     } else {                                              // edge row
 #pragma unroll
                         for (int h = 0; h < NR1; ++h) {
                             const int n = r0 + 2 * (h == NRF ? vt3 : tc + GT * h);
-                            const bool on = (h == NRF) ? act3 : true;      // (mirrors: max / min unharmed)
-                            const bool in0 = on && (n >= lo) && (n < hi);
-                            const bool in1 = on && (n + 1 >= lo) && (n + 1 < hi);
+                            const bool in0 = (n >= lo) && (n < hi);
+                            const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
                             const cpx v = d[R1 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
                             if (h == NRF) {
