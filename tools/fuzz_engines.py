@@ -321,7 +321,10 @@ def run_fused(cases, seed, verbose=True, n=32768):
                         print('   oracle there: idx', ro_['index'], 'chi2', ro_['chi2'], 'amp', ro_['amp'], flush=True)
                     assert flips.sum() <= max(1, 0.01 * flips.size), tag + f' slot {s} search {q}: {flips.sum()} bin flips'
                     if flips.any():
-                        assert np.allclose(a[ok][flips, o + 2], b[ok][flips, o + 2], rtol=1e-5), tag + f' flip is not a tie s{s} q{q}'
+                        # (an interpolated fit reports the chi2 of the parabola's vertex: two discrete bins that tie to
+                        # 1e-6 give vertices whose chi2 differ by the fp32 error of the neighbouring amplitudes)
+                        assert np.allclose(a[ok][flips, o + 2], b[ok][flips, o + 2], rtol=1e-4 if interp else 1e-5), \
+                            tag + f' flip is not a tie s{s} q{q}'
                     same = ~flips
                     da = np.abs(a[ok][same, o] - b[ok][same, o])
                     lim = 1e-4 * np.abs(b[ok][same, o]) + 2e-4 * fts[s].ampres
