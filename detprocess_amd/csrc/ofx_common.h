@@ -76,6 +76,9 @@ struct OfxSlotDev {
 struct OfxTdWinDev {
     int lo, hi;     // end-exclusive slice
     int out_off;
+    // register rows of the fused kernels (set per launch by the engine, whose row length they
+    // depend on): bit n1 of `full` = row n1 lies inside the slice, of `edge` = it is cut by it
+    unsigned full = 0, edge = 0;
 };
 
 struct OfxBandDev {

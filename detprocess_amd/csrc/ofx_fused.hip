@@ -755,11 +755,14 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
                 cpx s2 = mk(0.0f, 0.0f), sq2 = mk(0.0f, 0.0f);            // full rows, packed
+                // (row classification done by the host per launch: two bit tests per row instead of
+                // four compares)
+                const unsigned fullm = pd.tdw[w].full, anym = fullm | pd.tdw[w].edge;
 #pragma unroll
                 for (int n1 = 0; n1 < 32; ++n1) {
                     const int r0 = 1024 * n1;
-                    if (r0 + 1024 <= lo || r0 >= hi) continue;            // uniform: outside
-                    if (lo <= r0 && r0 + 1024 <= hi) {                    // uniform: full row
+                    if (!((anym >> n1) & 1u)) continue;                   // uniform: outside
+                    if ((fullm >> n1) & 1u) {                             // uniform: full row
 #pragma unroll
                         for (int h = 0; h < VT; ++h) {
                             // (dependent forms only: anything that is a function of d
@@ -1666,6 +1669,15 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     if (p->N != FN) return ofx_fused25_process(p, d_traces, d_valid, n, d_out, st);
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
+    for (int w = 0; w < pd.n_tdwin; ++w) {          // row classification of the window sums
+        pd.tdw[w].full = pd.tdw[w].edge = 0;
+        for (int n1 = 0; n1 < 32; ++n1) {
+            const int r0 = 1024 * n1, lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+            if (r0 + 1024 <= lo || r0 >= hi) continue;
+            if (lo <= r0 && r0 + 1024 <= hi) pd.tdw[w].full |= 1u << n1;
+            else pd.tdw[w].edge |= 1u << n1;
+        }
+    }
     int rc = fused_tables(p);
     if (rc) return rc;
     FusedTabs common;

@@ -546,11 +546,12 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                 // and of round 2 (sb, sqb: masked by `act3`); duplicates do not change max / min
                 float sa = 0.0f, sqa = 0.0f, sb = 0.0f, sqb = 0.0f, mx = -INFINITY, mn = INFINITY;
                 cpx s2a = mk(0.0f, 0.0f), sq2a = mk(0.0f, 0.0f), s2b = mk(0.0f, 0.0f), sq2b = mk(0.0f, 0.0f);
+                const unsigned fullm = pd.tdw[w].full, anym = fullm | pd.tdw[w].edge;
 #pragma unroll
                 for (int n1 = 0; n1 < R1; ++n1) {
                     const int r0 = ROWS * n1;
-                    if (r0 + ROWS <= lo || r0 >= hi) continue;            // uniform: outside
-                    if (lo <= r0 && r0 + ROWS <= hi) {                    // uniform: full row
+                    if (!((anym >> n1) & 1u)) continue;                   // uniform: outside
+                    if ((fullm >> n1) & 1u) {                             // uniform: full row
 #pragma unroll
                         for (int h = 0; h < NRF; ++h) {
                             // (dependent forms only, as in ofx_fused.hip)
@@ -1520,6 +1521,15 @@ int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
                         float* d_out, hipStream_t st) {
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
+    for (int w = 0; w < pd.n_tdwin; ++w) {          // row classification of the window sums
+        pd.tdw[w].full = pd.tdw[w].edge = 0;
+        for (int n1 = 0; n1 < R1; ++n1) {
+            const int r0 = ROWS * n1, lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+            if (r0 + ROWS <= lo || r0 >= hi) continue;
+            if (lo <= r0 && r0 + ROWS <= hi) pd.tdw[w].full |= 1u << n1;
+            else pd.tdw[w].edge |= 1u << n1;
+        }
+    }
     int rc = fused25_tables(p);
     if (rc) return rc;
     Tabs25 common;
