@@ -174,6 +174,7 @@ struct FusedTabs {
     float2 tb0hi;         // base of virtual thread 0 for its slots j >= 8 (block 512)
     float2 wq;            // W_{M/2}  (the self-paired bin k = M/2)
     float gq;             // g_{M/2}
+    unsigned rowmask;     // register rows n1 (1024 lags each) the slot's windowed searches touch
 };
 
 // One filter slot of a multi-slot launch (device array, read through scalar loads).
@@ -1105,6 +1106,48 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         if constexpr (FEAT & 1) {
             if (lane_t < OFX_MAX_SEARCHES) L.wc[lane_t][wave_t] = ofx_cand_none();
             constexpr int NPASS = SPLIT_EXCHANGE ? 2 : 1;   // SPLIT: even lags, then odd
+            // Narrow windows (the usual constrained fit: +-400 us is 1000 lags, one or two of the 32
+            // register rows of 1024 lags): only the rows the windowed searches touch are dumped,
+            // complex, in ONE pass (row n1 -> slot popcount(rowmask below n1); the host computes the
+            // mask per launch).  Wider or outside-window searches keep the dump of all lags.
+            const unsigned rmask = TBX.rowmask;
+            constexpr int NSLOT = (SPLIT_EXCHANGE ? XBUF_ELEMS : 2 * XBUF_ELEMS) / 1024;
+            if (SPLIT_EXCHANGE && !PP && __builtin_popcount(rmask) <= NSLOT) {
+                cpx* xc = reinterpret_cast<cpx*>(SH.xb);
+                __syncthreads();
+                int slotb = 0;                                   // uniform: slot * 512
+#pragma unroll
+                for (int n1 = 0; n1 < 32; ++n1) {
+                    if (!((rmask >> n1) & 1u)) continue;         // uniform
+#pragma unroll
+                    for (int h = 0; h < VT; ++h) xc[slotb + tt + FT * h] = d[32 * h + n1];
+                    slotb += 512;
+                }
+                __syncthreads();
+#pragma unroll 1
+                for (int q = 0; q < SDX.n_search; ++q) {
+                    const OfxSearchDev& sq = SDX.search[q];
+                    const bool full = !sq.outside && sq.lo == 0 && sq.hi == FN;
+                    if (sq.kind != OFX_SEARCH_DELAY || full) continue;
+                    OfxCand c = ofx_cand_none();
+                    auto scan = [&](int i0, int i1) {
+                        for (int i = i0 + tt; i < i1; i += FT) {
+                            const int n = (i - pre) & (FN - 1);
+                            const int n1 = n >> 10;
+                            const int sl = __builtin_popcount(rmask & ((1u << n1) - 1u));
+                            ofx_cand_take(c, SH.xb[sl * 1024 + (n & 1023)], i);
+                        }
+                    };
+                    if (sq.outside) {
+                        scan(0, sq.lo);
+                        scan(sq.hi, FN);
+                    } else {
+                        scan(sq.lo, sq.hi);
+                    }
+                    c = ofx_cand_wave_reduce(c);
+                    if (lane_t == 0) L.wc[q][wave_t] = c;
+                }
+            } else
             for (int e = 0; e < NPASS; ++e) {
                 __syncthreads();
 #pragma unroll
@@ -1710,6 +1753,23 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             if (sq.kind == OFX_SEARCH_DELAY &&
                 (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
                 feat |= 1;
+            if (sq.kind == OFX_SEARCH_DELAY && !(sq.lo == 0 && sq.hi == p->N && !sq.outside)) {
+                // register rows of the lags n = (i - pre) mod N the search visits
+                auto mark = [&](int i0, int i1) {
+                    for (int i = i0; i < i1;) {
+                        const int nl = (i - p->pre) & (FN - 1);
+                        a.tabs.rowmask |= 1u << (nl >> 10);
+                        i += 1024 - (nl & 1023);                 // first lag of the next row
+                    }
+                    if (i1 > i0) a.tabs.rowmask |= 1u << (((i1 - 1 - p->pre) & (FN - 1)) >> 10);
+                };
+                if (sq.outside) {
+                    mark(0, sq.lo);
+                    mark(sq.hi, FN);
+                } else {
+                    mark(sq.lo, sq.hi);
+                }
+            }
             if (sq.nlow > NS_MAX || (sq.nlow > NLOW_MAX && VT != 2)) {
                 ofx_set_error("FUSED engine: lowchi2_fcutoff covers %d bins (> %d)", sq.nlow,
                               VT == 2 ? NS_MAX : NLOW_MAX);
