@@ -179,11 +179,10 @@ __device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int s
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
-// (plain fmaxf / fminf: the compiler forms v_max3_f32 / v_min3_f32 itself.  The inline-asm forms of
-// ofx_fused.hip gave wrong SEARCH results in the <2, true> and <6, true> instantiations of this
-// kernel -- time-domain windows and several slots, no windowed fit: chi2_0 off by 1e-3, found by
-// tools/fuzz_engines.py -- and exact ones with these; tests/test_fused25.py sweeps every
-// instantiation against the oracle since.)
+// (plain fmaxf / fminf: the compiler forms v_max3_f32 / v_min3_f32 itself.  With the inline-asm forms
+// of ofx_fused.hip the <2, true> instantiation gave wrong SEARCH results and with these <6, true> still
+// did -- see the window sums in the kernel for what removed the problem, DESIGN.md section 5.1b for the
+// account; tests/test_fused25.py builds every instantiation against the oracle.)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }
 __device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
