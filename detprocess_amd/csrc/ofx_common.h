@@ -227,6 +227,15 @@ int ofx_fused12_fft_create(int n_complex, int device, void** h);      // rows of
 void ofx_fused12_fft_destroy(void* h);
 int ofx_fused12_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,
                          hipStream_t st);
+// ofx_fused20.hip: the same source built for 20000-sample traces
+bool ofx_fused20_supported(int n_samples);
+int ofx_fused20_prepare_slot(ofx_plan* p, int slot, const double* wf);
+int ofx_fused20_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
+                        long long n, float* d_out, hipStream_t st);
+int ofx_fused20_fft_create(int n_complex, int device, void** h);      // rows of 10000 complex points
+void ofx_fused20_fft_destroy(void* h);
+int ofx_fused20_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,
+                         hipStream_t st);
 // ofx_fused12.hip: the same source built for 12500-sample traces
 bool ofx_fused12_supported(int n_samples);
 int ofx_fused12_prepare_slot(ofx_plan* p, int slot, const double* wf);

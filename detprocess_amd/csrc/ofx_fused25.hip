@@ -52,13 +52,17 @@ namespace {
 #define OFX25_FN(x) ofx_fused25_##x
 #define k_fused25 k_fused25
 #define k_fft25 k_fft25
+#elif OFX25_R1 == 16
+#define OFX25_FN(x) ofx_fused20_##x
+#define k_fused25 k_fused20
+#define k_fft25 k_fft20
 #else
 #define OFX25_FN(x) ofx_fused12_##x
 #define k_fused25 k_fused12
 #define k_fft25 k_fft12
 #endif
 constexpr int R1 = OFX25_R1, R2 = 25, R3 = 25;
-static_assert(R1 == 20 || R1 == 10, "supported first-stage lengths");
+static_assert(R1 == 20 || R1 == 16 || R1 == 10, "supported first-stage lengths");
 constexpr int GM = R1 * R2 * R3;        // 12500 packed complex points
 constexpr int GN = 2 * GM;              // 25000 samples
 constexpr int GP = R1 * R2;             // 500 blocks of R3 bins
@@ -326,11 +330,11 @@ __device__ __forceinline__ void t1_apply(cpx (&d)[NV], const T1Anch& an) {
     A[2] = hi2(an.q[1]);
     if constexpr (R1 > 15) A[3] = cmul(A[1], A[2]);
 #pragma unroll
-    for (int a = 0; a < R1 / 5; ++a)
+    for (int a = 0; a < (R1 + 4) / 5; ++a)
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
             const int k1 = 5 * a + b;
-            if (k1 == 0) continue;
+            if (k1 == 0 || k1 >= R1) continue;
             const cpx w = (a == 0) ? B[b] : (b == 0) ? A[a] : cmul(A[a], B[b]);
             d[O + k1] = CONJ ? cmulc(d[O + k1], w) : cmul(d[O + k1], w);
         }
@@ -356,6 +360,7 @@ __device__ __forceinline__ float lowchi2_term(int k, int dl, float amp, cpx x2, 
 template <int DIR, int OFF>
 __device__ __forceinline__ void dft_r1(cpx (&d)[NV]) {
     if constexpr (R1 == 20) dft20<DIR, NV, OFF>(d);
+    else if constexpr (R1 == 16) dft<16, DIR, NV, OFF>(d);
     else dft10<DIR, NV, OFF>(d);
 }
 // the full rounds of F1 / I1: first-stage transforms and inter-stage twiddles of rounds H .. NRF-1
@@ -885,7 +890,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
         const int vt3t = min(max(tt - I3T, 0) + NRF * GT, NV1 - 1);
         const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(SDX.s, NLOW_MAX * 8);
         const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(SDX.g, NLOW_MAX * 4);
-        constexpr int GS = 10;                     // registers per group (two groups per round)
+        constexpr int GS = (R1 == 10) ? 10 : R1 / 2;   // registers per group (two groups per round)
         constexpr int NG = NV / GS;
         float gm[NG];
         float mloc = 0.0f;

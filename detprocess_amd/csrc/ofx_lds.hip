@@ -966,6 +966,10 @@ int ofx_ldsfft_create(int n_complex, int device, OfxLdsFft** out, bool allow_reg
             kind = 12;
             r = ofx_fused12_fft_create(n_complex, device, &h);
         }
+        if (r == OFX_ERR_UNSUPPORTED) {
+            kind = 20;
+            r = ofx_fused20_fft_create(n_complex, device, &h);
+        }
         if (r == OFX_OK) {
             OfxLdsFft* f = new OfxLdsFft();
             f->reg = h;
@@ -1009,6 +1013,7 @@ void ofx_ldsfft_destroy(OfxLdsFft* f) {
     if (f->reg_kind == 32) ofx_fused_fft_destroy(f->reg);
     if (f->reg_kind == 25) ofx_fused25_fft_destroy(f->reg);
     if (f->reg_kind == 12) ofx_fused12_fft_destroy(f->reg);
+    if (f->reg_kind == 20) ofx_fused20_fft_destroy(f->reg);
     if (f->d_tw) (void)hipFree(f->d_tw);
     if (f->d_pos) (void)hipFree(f->d_pos);
     delete f;
@@ -1020,6 +1025,7 @@ int ofx_ldsfft_exec(OfxLdsFft* f, bool forward, const float2* in, float2* out, l
     if (f->reg_kind == 32) return ofx_fused_fft_exec(f->reg, forward, in, out, rows, st);
     if (f->reg_kind == 25) return ofx_fused25_fft_exec(f->reg, forward, in, out, rows, st);
     if (f->reg_kind == 12) return ofx_fused12_fft_exec(f->reg, forward, in, out, rows, st);
+    if (f->reg_kind == 20) return ofx_fused20_fft_exec(f->reg, forward, in, out, rows, st);
     const bool big = f->g.M >= 1024;
     int max_r = 2;
     for (int i = 0; i < f->g.nfac; ++i) max_r = std::max(max_r, f->g.fac[i]);

@@ -38,11 +38,12 @@ enum { OFX_MEM_HOST = 0, OFX_MEM_DEVICE = 1 };
 /* engines: FUSED = one persistent LDS-resident FFT kernel per trace
  *          ROCFFT = rocFFT R2C -> filter kernel -> rocFFT C2R -> arg-max kernel
  *          AUTO = FUSED where the trace length is supported, else ROCFFT     */
-enum { OFX_ENGINE_AUTO = 0,     /* FUSED if n_samples is 32768, 25000 or 12500, else LDS if it applies, else ROCFFT */
+enum { OFX_ENGINE_AUTO = 0,     /* FUSED if n_samples is 32768, 25000, 20000 or 12500, else LDS if it applies, else ROCFFT */
        OFX_ENGINE_FUSED = 1,    /* register/LDS-resident kernels: n_samples == 32768 (k_fused),
                                    25000 and 12500 (k_fused25 / k_fused12: the 20 ms and 10 ms traces
-                                   of the reference's examples at 1.25 MHz; lowchi2 cut-offs and psd_amp
-                                   bands up to 62 kHz = 1250 / 625 bins, beyond that AUTO plans fall back) */
+                                   of the reference's examples at 1.25 MHz) and 20000 (k_fused20);
+                                   lowchi2 cut-offs and psd_amp bands up to 62 kHz = 1250 / 1000 / 625
+                                   bins, beyond that AUTO plans fall back                         */
        OFX_ENGINE_ROCFFT = 2,   /* rocFFT pipeline, any even n_samples                         */
        OFX_ENGINE_LDS = 3 };    /* LDS-resident kernel, n_samples/2 = 2^a 3^b 5^c, <= 34816    */
 

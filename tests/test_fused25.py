@@ -15,7 +15,7 @@ FS = 1.25e6
 N = 25000
 
 
-@pytest.fixture(autouse=True, params=[25000, 12500])
+@pytest.fixture(autouse=True, params=[25000, 12500, 20000])
 def _trace_length(request):
     global N
     N = request.param

@@ -13,7 +13,7 @@ from detprocess_amd import build_filter, synth
 pytestmark = pytest.mark.gpu
 
 FS = 1.25e6
-ENGINES = [(32768, "fused"), (32768, "rocfft"), (32768, "lds"), (25000, "lds"), (25000, "fused"), (12500, "fused"), (4096, "lds"),
+ENGINES = [(32768, "fused"), (32768, "rocfft"), (32768, "lds"), (25000, "lds"), (25000, "fused"), (12500, "fused"), (20000, "fused"), (4096, "lds"),
            (4096, "rocfft"), (1000, "rocfft")]
 
 

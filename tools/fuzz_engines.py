@@ -437,6 +437,8 @@ if __name__ == '__main__':
         bad = run_fused(cases, seed, n=25000)
     elif len(sys.argv) > 3 and sys.argv[3] == 'fused12':
         bad = run_fused(cases, seed, n=12500)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'fused20':
+        bad = run_fused(cases, seed, n=20000)
     elif len(sys.argv) > 3 and sys.argv[3] == 'adc':
         bad = run_adc(cases, seed)
     else:
