@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- traces/s of the of1x1 hot path on MI355X (BASELINE.json metric).
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it is
-launched under torch.distributed.run, one rank per GPU (RCCL).  One "step" = one
+Contract (driver): python bench.py --gpus N --steps K --warmup W ; for N > 1 it runs one rank per
+GPU (RCCL) under torch.distributed.run -- either launched that way by the driver (WORLD_SIZE set)
+or, when started as plain `python bench.py --gpus N`, by launching itself: the parent starts the
+N ranks as a child process before it has touched the GPU, relays rank 0's JSON line and exits with
+the child's code (the reference's fan-out: Pool.starmap over series, features.py:405-420).  One "step" = one
 pass of the hot path over the resident batch of synthetic events (already in HBM when
 the timed region starts).  Event batches are sharded across ranks by
 ``detprocess_amd.dist.run_sharded`` (weak scaling: every rank owns --traces traces); the
@@ -219,6 +222,25 @@ def metric_name():
         return fallback
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start the N ranks under
+    torch.distributed.run as a CHILD process (never exec: this process must not have touched the
+    GPU, and does not), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL over xGMI)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     global N_SAMPLES
     ap = argparse.ArgumentParser()
@@ -237,6 +259,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
     N_SAMPLES = args.samples
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist

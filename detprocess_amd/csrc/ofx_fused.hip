@@ -171,7 +171,7 @@ struct FusedTabs {
     const float4* midW;   // [16][512]  (W_k / 2, conj(W_p) / 2)          slot j, virtual thread v
     const float2* midG;   // [16][512]  (g_k', g_p')
     const float2* tbase;  // [512]      T_v = i exp(-2 pi i v / N); T of slot j is T_v w_32^j
-    float2 tb0hi;         // base of virtual thread 0 for its slots j >= 8 (block 512)
+    float2 tb0hi;         // base of virtual thread 0 for its slots j >= 8 (block 512); read from the kernel ARGUMENT only (ofx_fused25.hip, Tabs25::tb0hi)
     float2 wq;            // W_{M/2}  (the self-paired bin k = M/2)
     float gq;             // g_{M/2}
     unsigned rowmask;     // register rows n1 (1024 lags each) the slot's windowed searches touch
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
             cpx* xs = reinterpret_cast<cpx*>(SH.xb) + tl;
             const cpx tb = buf_ld2(rtb, tl * 8, 0);
-            const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
+            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;   // (the kernel argument: see Tabs25::tb0hi)
             __syncthreads();                   // every E2 read is done: the buffer is free
 #pragma unroll
             for (int j = 0; j < 16; ++j) xs[j * FT] = d[16 + j];
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             const cpx a8 = d[8];
             if (wave == 0) perm_in<0>(d, tl == 0, L.perm);
             const cpx tb = buf_ld2(rtb, tl * 8, 0);
-            const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
+            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;   // (the kernel argument: see Tabs25::tb0hi)
             chi2v = middle_slots<0, WIDE>(d, rmid, tl, L, tb, tbh, chi2v);
             if (wave == 0) chi2v = perm_out<0>(d, tl == 0, a8, TBX, chi2v, L.perm);
             dft<16, +1, NV, 0>(d);

@@ -159,7 +159,15 @@ struct Tabs25 {
     const float4* midW;   // [25][256]  (W_k / 2, conj(W_p) / 2)   slot J, thread v
     const float2* midG;   // [25][256]  (g_k', g_p')
     const float2* tbase;  // [256]      T_v = i exp(-2 pi i v / N); T of slot J is T_v w_50^J
-    float2 tb0hi;         // base of thread 0 for its slots J >= 13 (block 250)
+    // Base of thread 0 for its slots J >= 13 (block 250); a constant of the geometry.  The kernel reads
+    // it from its ARGUMENT `tabs`, never from the per-slot copy in global memory: with
+    // `(tl == 0) ? slots[i].tabs.tb0hi : tb` the compiler sank the scalar load into an if / else, and
+    // in the flow block of that if / else the register allocator put live-range-split copies ABOVE
+    // the instruction that restores EXEC (behind a rematerialised s_movk_i32, where
+    // SIInstrInfo::isBasicBlockPrologue stops looking), so thread 0 alone kept stale values in some
+    // of its 50 registers: round 2's wrong <2, true> / <6, true> (DESIGN.md section 5.1b;
+    // tools/isa_hazards.py `execprologue` finds the pattern in the ISA, `make check`).
+    float2 tb0hi;
     unsigned rowmask;     // register rows n1 (1250 lags each) the slot's windowed searches touch
     float2 wq;            // W_{M/2}
     float gq;             // g_{M/2}
@@ -183,10 +191,7 @@ __device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int s
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
-// (plain fmaxf / fminf: the compiler forms v_max3_f32 / v_min3_f32 itself.  With the inline-asm forms
-// of ofx_fused.hip the <2, true> instantiation gave wrong SEARCH results and with these <6, true> still
-// did -- see the window sums in the kernel for what removed the problem, DESIGN.md section 5.1b for the
-// account; tests/test_fused25.py builds every instantiation against the oracle.)
+// (plain fmaxf / fminf: the compiler forms v_max3_f32 / v_min3_f32 itself)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }
 __device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
@@ -568,10 +573,9 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                         if constexpr (PART) {
                             // (every wave, no branch: the waves without a third round hold a copy of
                             // virtual thread 624 there, see load_rows; sums are masked by `act3` at
-                            // the end, copies cannot change max / min.  A wave-uniform branch around
-                            // these lines made the <2, true> / <6, true> instantiations compute wrong
-                            // SEARCH results -- the same on every run, cause not found;
-                            // tests/test_fused25.py builds every instantiation since.)
+                            // the end, copies cannot change max / min.  Measured against the form with
+                            // a wave-uniform branch around these lines, round 3, same box: 13.5
+                            // against 12.1 M traces/s with five windows.)
                             const cpx v = d[NRF * R1 + n1];
                             s2b = s2b + v;
                             sq2b = pfma(v, v, sq2b);
@@ -754,7 +758,9 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
             const cpx aself = d[R3 + 12];
             if (wave == 0) perm_in(d, tl == 0, L.perm);
             const cpx tb = buf_ld2(rtb, tc * 8, 0);
-            const cpx tbh = (tl == 0) ? mk(TBX.tb0hi.x, TBX.tb0hi.y) : tb;
+            // (tabs.tb0hi is a kernel argument -- the same for every slot -- so that this is a
+            // select on two registers, not an if / else around a load: see the note at Tabs25::tb0hi)
+            const cpx tbh = (tl == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
             chi2v = middle_slots(d, rmid, tc, L, tb, tbh, chi2v);
             if (wave == 0) chi2v = perm_out(d, tl == 0, aself, TBX, chi2v, L.perm);
         }

@@ -28,8 +28,8 @@ def gather_features(local, total, rank, world, group=None):
     Shards may differ by one row, so rows are padded to the largest shard for
     the collective and trimmed afterwards.
     """
-    if world == 1:
-        return local
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return local           # (with a process group, world 1 still goes through the collective)
     sizes = [shard_range(total, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
     F = local.shape[1]

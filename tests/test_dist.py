@@ -100,3 +100,23 @@ def test_two_rank_gloo_equals_single_process(total, chunk):
     r = orc.process_events(filt, traces, "unconstrained")
     want = np.stack([r["amp"], r["t0"], r["chi2"], r["lowchi2"]], axis=1)
     assert np.array_equal(got, want)          # pure sharding: bit-identical
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts its two ranks under
+    torch.distributed.run as a child process and passes their exit code on: on a box without a
+    GPU every rank stops at "needs a GPU", never at "needs torch.distributed.run"."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("the CPU form of this check")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    text = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert text.count("bench.py needs a GPU") == 2, text[-2000:]
+    assert "needs torch.distributed.run" not in text

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the
 fp64 oracle on the same seeded inputs, plus edge cases and size-independent
 properties at larger batch sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -607,6 +609,50 @@ def test_run_sharded_streaming_equals_resident():
     ref = orc.process_events(orc.OFFilter(tmpl, psd, FS, pre), shard[:16].cpu().numpy().astype(np.float64),
                              "unconstrained")
     check_search(want[:16].cpu().numpy().astype(np.float64), 0, ref, "", ft.ampres, FS, "sharded")
+
+
+def test_run_sharded_gathers_over_rccl_at_world_one():
+    """The `nccl` (= RCCL) branch of the sharded driver, executed for real: a process group of one
+    rank on the GPU, `run_sharded(gather=True)` -> `all_gather_into_tensor` on RCCL (the path's
+    only collective); the gathered matrix is bit for bit the local one.
+    (More ranks need more GPUs than a test box has: the world-2 form runs on gloo in
+    tests/test_dist.py through the same function.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from detprocess_amd import OFPlan, SynthSource, build_filter
+    from detprocess_amd import dist as ofdist
+    n, pre = 32768, 16384
+    tmpl = synth.make_template(n, pre, FS)
+    psd = synth.make_psd(n, FS)
+    ft = build_filter(tmpl, psd, FS, pre)
+    gen = SynthSource(n, tmpl, psd, FS, 3 * ft.ampres, 300 * ft.ampres, 0.5, 2000, seed=6)
+    plan = OFPlan(n, pre, FS, max_batch=4096, engine="fused")
+    plan.set_filter(0, ft)
+    plan.add_search(0, "delay")
+    row = plan.row_floats
+    total = 300
+    proc = lambda ev, out: plan.process(ev, out=out)
+    local = ofdist.run_sharded(total, 128, gen.fill, proc, row, (n,), device="cuda:0",
+                               gather=False).clone()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        got = ofdist.run_sharded(total, 128, gen.fill, proc, row, (n,), rank=0, world=1,
+                                 device="cuda:0", gather=True)
+        torch.cuda.synchronize()
+        assert got.data_ptr() != local.data_ptr() and got.shape == local.shape
+        assert torch.equal(got, local)
+        # ragged form (padding + trim) of the same collective
+        g2 = ofdist.gather_features(local[:7], 7, 0, 1)
+        assert torch.equal(g2, local[:7])
+    finally:
+        dist.destroy_process_group()
+    plan.close()
 
 
 def test_rejected_filter_table_leaves_the_plan_as_it_was():
