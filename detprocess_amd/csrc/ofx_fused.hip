@@ -116,7 +116,11 @@ struct FusedShared {               // one per workgroup
 struct FusedLds {                  // one per trace in flight (per half)
     cpx xlow[NLOW_MAX + 8];        //  4,160 B   2*X_k for k < 512 (lowchi2)
     float red[4][NWAVE];           // per-wave partials
-    float tdred[OFX_MAX_TDWIN][4][NWAVE];   // time-domain window partials
+    // time-domain window partials, double-buffered by trace parity: a plan with windows and no
+    // search has no barrier between thread w's reads of one trace and the other waves' writes of
+    // the next (a barrier on that path costs every kernel with windows ~420 B of scratch per lane:
+    // it splits the region the prefetched trace lives in)
+    float tdred[2][OFX_MAX_TDWIN][4][NWAVE];
     OfxCand cand[NWAVE];
     OfxCand wc[OFX_MAX_SEARCHES][NWAVE];    // per-wave winners of the windowed searches
     OfxCand fin[OFX_MAX_SEARCHES];          // resolved fit per search
@@ -152,7 +156,14 @@ __device__ __forceinline__ void ofx_stamp_id(unsigned long long* p) {
                  "s_store_dword %0, %2, 0x68\n\ts_store_dword %1, %2, 0x70"
                  : "=&s"(a), "=&s"(b) : "s"(p));
 }
-#define STAMP(i)                                                                              \
+// -DOFX_TAILSTAMPS (with -DOFX_STAMPS): the stamps 2..9 of the transform phases are dropped and their
+// slots carry the sub-phases of the tail instead (TSTAMP(2..9); tools/dev_tail_timeline.py).
+#ifdef OFX_TAILSTAMPS
+constexpr bool TAILMODE = true;
+#else
+constexpr bool TAILMODE = false;
+#endif
+#define STAMP_AT(i)                                                                           \
     do {                                                                                      \
         asm volatile(";ofxphase " #i);                                                        \
         {   /* no branch: traces beyond the last slot keep overwriting it */                  \
@@ -163,6 +174,17 @@ __device__ __forceinline__ void ofx_stamp_id(unsigned long long* p) {
             if ((i) == 12) ++stamp_it;                                                        \
         }                                                                                     \
     } while (0)
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        if constexpr (!(TAILMODE && (i) >= 2 && (i) <= 9)) STAMP_AT(i);                       \
+    } while (0)
+#define TSTAMP(i)                                                                             \
+    do {                                                                                      \
+        if constexpr (TAILMODE) STAMP_AT(i);                                                  \
+    } while (0)
+#endif
+#ifndef TSTAMP
+#define TSTAMP(i)
 #endif
 
 struct FusedTabs {
@@ -677,6 +699,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     // registers of the current one are dead (after the arg-max), so that its HBM
     // latency hides under the rest of the tail; `have` = d already holds trace b.
     bool have = false;
+    [[maybe_unused]] int tdpar = 0;          // parity of the trace count: which half of L.tdred is written
 #ifdef OFX_STAMPS
     int stamp_it = 0;
     unsigned long long* stamp_base;
@@ -735,6 +758,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         // covers whole rows n1 (uniform test, unmasked adds / max3 / min3), at most two
         // partial rows (masked), and rows outside it are skipped.
         if constexpr (FEAT & 2) {
+            tdpar ^= 1;
             // end points of the slice owned by thread w (trapezoid correction): requested
             // first, consumed after the reductions
             float first = 0.f, last = 0.f;
@@ -775,11 +799,17 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                             mn = min3f(mn, v.x, v.y);
                         }
                     } else {                                              // edge row
+                        // (the sample index against the window, as the thread's offset in the row
+                        // against SCALAR bounds: with `n = r0 + 2 (tl + FT h)` per row the compiler
+                        // hoisted all 128 values of n, n + 1 out of the window loop -- 470 B of
+                        // scratch per lane in every kernel with windows, 80 scratch reloads per
+                        // trace each behind an s_waitcnt vmcnt(0))
+                        const int lo_r = lo - r0, hi_r = hi - r0;         // uniform
 #pragma unroll
                         for (int h = 0; h < VT; ++h) {
-                            const int n = r0 + 2 * (tl + FT * h);
-                            const bool in0 = (n >= lo) && (n < hi);
-                            const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                            const int c = 2 * (tl + FT * h);              // offset in the row
+                            const bool in0 = (c >= lo_r) && (c < hi_r);
+                            const bool in1 = (c >= lo_r - 1) && (c < hi_r - 1);
                             const cpx v = d[32 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
                             s = (s + y0) + y1;
@@ -794,10 +824,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                 mx = ofx_wave_max(mx);
                 mn = ofx_wave_min(mn);
                 if (lane == 0) {
-                    L.tdred[w][0][wave] = s;
-                    L.tdred[w][1][wave] = mx;
-                    L.tdred[w][2][wave] = mn;
-                    L.tdred[w][3][wave] = sq;
+                    L.tdred[tdpar][w][0][wave] = s;
+                    L.tdred[tdpar][w][1][wave] = mx;
+                    L.tdred[tdpar][w][2][wave] = mn;
+                    L.tdred[tdpar][w][3][wave] = sq;
                 }
             }
             __syncthreads();
@@ -806,10 +836,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float S = 0.f, SQ = 0.f, MX = -INFINITY, MN = INFINITY;
                 for (int q = 0; q < NWAVE; ++q) {
-                    S += L.tdred[w][0][q];
-                    MX = fmaxf(MX, L.tdred[w][1][q]);
-                    MN = fminf(MN, L.tdred[w][2][q]);
-                    SQ += L.tdred[w][3][q];
+                    S += L.tdred[tdpar][w][0][q];
+                    MX = fmaxf(MX, L.tdred[tdpar][w][1][q]);
+                    MN = fminf(MN, L.tdred[tdpar][w][2][q]);
+                    SQ += L.tdred[tdpar][w][3][q];
                 }
                 float* o = row + pd.tdw[w].out_off;
                 o[OFX_TD_BASELINE] = S / (float)(hi - lo);
@@ -1042,6 +1072,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                 rs_g, (tt + FT * i) * 4, 0, 0));
         }
+        TSTAMP(2);                               // group maxima, table requests
         {
             const float wmax = ofx_wave_max(mloc);
             const float wchi = ofx_wave_sum(chi0p);
@@ -1063,6 +1094,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         // one register each from here on (the sums would otherwise be sunk to their uses
         // with every per-wave partial kept alive)
         asm volatile("" : "+v"(Mstar), "+v"(chi0), "+v"(a_lag0));
+        TSTAMP(3);                               // block maximum and chi2_0
 
         // full-range delay fit: the thread(s) holding the maximum resolve the
         // smallest rolled index among their lags with A^2 == max
@@ -1100,6 +1132,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             fullbest = ofx_cand_block_reduce(fullbest, L.cand, tt, NWAVE);
         }
 
+        TSTAMP(4);                               // full-range arg-max
         // windowed / outside-window fits scan the lag dump: one use of the exchange buffer,
         // two barrier-delimited segments (dump | scans of every windowed search, each wave
         // keeping its winner per search in L.wc; the waves' winners are merged by resolve)
@@ -1192,6 +1225,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             __syncthreads();
         }
 
+        TSTAMP(5);                               // lag dump and window scans
         // psd_amp bands from the stashed 2 X_k (LDS below NLOW_MAX, the global stash above);
         // one wave per band
         const __amdgpu_buffer_rsrc_t rxw =
@@ -1264,6 +1298,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             }
             __syncthreads();
         }
+        TSTAMP(6);                               // bands, interpolation
         // Per search: every thread's share of the low-frequency chi2 (the last consumers of
         // VMEM-loaded values), parked per wave in LDS ...
 #pragma unroll 1
@@ -1293,6 +1328,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             if (lane_t == 0) L.lowp[q][wave_t] = low;
             if (tt == 0) L.fin[q] = best;
         }
+        TSTAMP(7);                               // low-frequency chi2, bins in LDS
         // ... WIDE: the bins from NLOW_MAX up, in chunks of WCH per thread read back from the
         // stash (entries of the partner blocks are conjugated, see MidRsrc) with their table
         // rows; every search with a cut-off beyond the chunk's first bin adds its share
@@ -1359,6 +1395,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                 if (SDX.search[q].interp) rp = &L.ref[q];
             ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
         }
+        TSTAMP(8);                               // barrier, row write
         // d and every table value are dead: request the next trace; its HBM latency hides
         // under the loop overhead and the first stages of the other workgroup
         if (MULTI && slot_i + 1 < slot_n) {
@@ -1684,11 +1721,11 @@ static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlo
                        const FusedTabs& tabs, const float* d_traces, const uint8_t* d_valid,
                        long long n, float* d_out, hipStream_t st, const FusedSlotArg* d_slots,
                        int nslots, int nstash) {
-#ifdef OFX_QUICK      // development builds: only the headline variant is compiled
-    if (feat == 0 && !MULTI)
-        return launch<0, false>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots, nslots,
-                                nstash);
-    ofx_set_error("OFX_QUICK build: only the FEAT = 0 single-slot kernel exists");
+#ifdef OFX_QUICK      // development builds: only one variant is compiled (-DOFX_QUICK=<feat>, 0 = headline)
+    if (feat == (OFX_QUICK + 0) && !MULTI)
+        return launch<OFX_QUICK + 0, false>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
+                                            nslots, nstash);
+    ofx_set_error("OFX_QUICK build: only the FEAT = %d single-slot kernel exists", OFX_QUICK + 0);
     return OFX_ERR_UNSUPPORTED;
 #else
 #define OFX_CASE(F)                                                                            \

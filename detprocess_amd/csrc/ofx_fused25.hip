@@ -114,7 +114,7 @@ struct Shared25 {
 struct Lds25 {
     cpx xlow[NLOW_MAX + 6];        // 2 X_k for k < 1250
     float red[4][NWAVE];
-    float tdred[OFX_MAX_TDWIN][4][NWAVE];
+    float tdred[2][OFX_MAX_TDWIN][4][NWAVE];   // double-buffered by trace parity (see ofx_fused.hip)
     OfxCand cand[NWAVE];
     OfxCand wc[OFX_MAX_SEARCHES][NWAVE];
     OfxCand fin[OFX_MAX_SEARCHES];
@@ -500,6 +500,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
     auto pass2 = [](int h, int k2) { return k2 < 12 ? 0 : (k2 > 12 ? 1 : h); };
 
     bool have = false;
+    [[maybe_unused]] int tdpar = 0;          // parity of the trace count: which half of L.tdred is written
 #ifdef OFX_STAMPS
     int stamp_it = 0;
     unsigned long long* stamp_base;
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
         // ------------------------------------------------ time-domain windows
         // Sample index of d[20 h + n1].{x,y} is 1250 n1 + 2 vt + {0,1}, vt = tid + 250 h.
         if constexpr (FEAT & 2) {
+            tdpar ^= 1;
             float first = 0.f, last = 0.f;
             if (tid < pd.n_tdwin) {
                 const int lo = pd.tdw[tid].lo, hi = pd.tdw[tid].hi;
@@ -583,11 +585,13 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                             mn = min3f(mn, v.x, v.y);
                         }
                     } else {                                              // edge row
+                        // (offsets in the row against scalar bounds: see the same lines of ofx_fused.hip)
+                        const int lo_r = lo - r0, hi_r = hi - r0;         // uniform
 #pragma unroll
                         for (int h = 0; h < NR1; ++h) {
-                            const int n = r0 + 2 * (h == NRF ? vt3 : tc + GT * h);
-                            const bool in0 = (n >= lo) && (n < hi);
-                            const bool in1 = (n + 1 >= lo) && (n + 1 < hi);
+                            const int c = 2 * (h == NRF ? vt3 : tc + GT * h);
+                            const bool in0 = (c >= lo_r) && (c < hi_r);
+                            const bool in1 = (c >= lo_r - 1) && (c < hi_r - 1);
                             const cpx v = d[R1 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
                             if (h == NRF) {
@@ -609,10 +613,10 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                 mx = ofx_wave_max(mx);
                 mn = ofx_wave_min(mn);
                 if ((tl & 63) == 0) {
-                    L.tdred[w][0][wave] = s;
-                    L.tdred[w][1][wave] = mx;
-                    L.tdred[w][2][wave] = mn;
-                    L.tdred[w][3][wave] = sq;
+                    L.tdred[tdpar][w][0][wave] = s;
+                    L.tdred[tdpar][w][1][wave] = mx;
+                    L.tdred[tdpar][w][2][wave] = mn;
+                    L.tdred[tdpar][w][3][wave] = sq;
                 }
             }
             __syncthreads();
@@ -621,10 +625,10 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float S = 0.f, SQ = 0.f, MX = -INFINITY, MN = INFINITY;
                 for (int q = 0; q < NWAVE; ++q) {
-                    S += L.tdred[w][0][q];
-                    MX = fmaxf(MX, L.tdred[w][1][q]);
-                    MN = fminf(MN, L.tdred[w][2][q]);
-                    SQ += L.tdred[w][3][q];
+                    S += L.tdred[tdpar][w][0][q];
+                    MX = fmaxf(MX, L.tdred[tdpar][w][1][q]);
+                    MN = fminf(MN, L.tdred[tdpar][w][2][q]);
+                    SQ += L.tdred[tdpar][w][3][q];
                 }
                 float* o = row + pd.tdw[w].out_off;
                 o[OFX_TD_BASELINE] = S / (float)(hi - lo);
