@@ -93,19 +93,64 @@ def filter_data3(pre):
 def measured_traffic(tag, traces_per_launch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*traffic.json,
     FETCH_SIZE / WRITE_SIZE collected separately and corrected as MI355X_MICROARCH.md
-    prescribes); scaled to this run's traces per launch.  None if no matching profile."""
+    prescribes); scaled to this run's traces per launch.  (bytes, source file) -- it is the stored
+    figure of the profiled run of the same workload, not a measurement of THIS run: the counters
+    need rocprofv3 around the process.  (None, None) if no matching profile."""
     import glob
-    best = None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json"))):
         try:
             rec = json.load(open(f))
         except Exception:
             continue
         if rec.get("workload", "config1") == tag and "hbm_bytes_per_trace" in rec:
-            best = rec
+            best, src = rec, os.path.relpath(f, ROOT)
     if best is None:
-        return None
-    return best["hbm_bytes_per_trace"] * traces_per_launch
+        return None, None
+    return best["hbm_bytes_per_trace"] * traces_per_launch, src
+
+
+def secondary_ceiling(tag, traces_per_s, n_gpus):
+    """The ceiling that actually binds the fused kernel: VALU issue.  Every CU issues at most one
+    VALU wave-instruction per cycle (four SIMDs, four cycles per 64-lane instruction, packed fp32
+    included), so the chip peaks at 256 x clock wave-instructions/s.  `insts_per_trace` is
+    SQ_INSTS_VALU of the committed counter pass (profiles/*sq_counters*.json), `clock_mhz` the shader
+    clock INSIDE the kernel from the stamped build (d s_memtime / d s_memrealtime,
+    profiles/*phase_timeline*.json) -- both stored figures of profiled runs of this workload, named in
+    `source`; `achieved` is this run's rate times insts_per_trace."""
+    import glob
+    sq = clk = None
+    src = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.json"))):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        wl = rec.get("workload")
+        if wl is None:                             # round-1/2 files: the kernel name tells
+            k = rec.get("kernel", "")
+            wl = "config1" if k.startswith("k_fused<") else ("config1_n25000" if "k_fused25" in k else None)
+        if wl == tag and "SQ_INSTS_VALU" in rec.get("per_trace", {}):
+            sq, sqf = rec["per_trace"]["SQ_INSTS_VALU"], os.path.relpath(f, ROOT)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*phase_timeline*.json"))):
+        try:
+            rec = json.load(open(f))
+        except Exception:
+            continue
+        if rec.get("workload", "config1") == tag and isinstance(rec.get("clock_mhz"), dict):
+            clk, clkf = rec["clock_mhz"]["mean"], os.path.relpath(f, ROOT)
+    if sq is None:
+        return None, None
+    ach = traces_per_s * sq                       # VALU wave-instructions per second, whole job
+    out = {"bound": "valu_issue", "insts_per_trace": sq, "achieved": ach / 1e9,
+           "unit": "G wave-instructions/s", "source": [sqf]}
+    if clk is not None:
+        peak = 256.0 * n_gpus * clk * 1e6
+        out.update({"peak": peak / 1e9, "frac": ach / peak, "clock_mhz": clk})
+        out["source"].append(clkf)
+    else:
+        out.update({"peak": None, "frac": None, "clock_mhz": None})
+    return out, clk
 
 
 def _cpu_setup():
@@ -419,6 +464,9 @@ def main():
         k_ms = sum(ms * n for ms, n in kt) / max(1, k_n)          # average launch duration
         traces_per_launch = n_local * C * args.steps / max(1, k_n)
         ach = traces_per_launch * algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms else 0.0
+        wtag = f"config{args.config}" + ("" if N_SAMPLES == 32768 else f"_n{N_SAMPLES}")
+        traffic, traffic_src = measured_traffic(wtag, traces_per_launch)
+        secondary, clock_mhz = (None, None) if streaming else secondary_ceiling(wtag, value, world)
         rec = {
             "metric": metric_name(),
             "value": value, "unit": "traces/s", "n_gpus": world, "steps": args.steps,
@@ -438,8 +486,8 @@ def main():
                                       f"of the feature matrix per pass"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(f"config{args.config}" + ("" if N_SAMPLES == 32768 else f"_n{N_SAMPLES}"),
-                                                     traces_per_launch),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "secondary": secondary, "clock_mhz": clock_mhz,
                          "kernel_ms": k_ms, "launches": k_n,
                          "traces_per_launch": traces_per_launch,
                          "algorithmic_bytes_per_trace": algo_bytes},

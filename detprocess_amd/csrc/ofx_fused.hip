@@ -150,6 +150,14 @@ __device__ __forceinline__ void ofx_stamp(unsigned long long* p) {
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0"
                  : "=&s"(t) : "s"(p));
 }
+// slot 15: the constant 100 MHz counter at stamp 0 -- shader clock in the kernel =
+// d(s_memtime) / d(s_memrealtime) x 100 MHz between the stamps 0 of consecutive traces
+// (MI355X_MICROARCH.md, DVFS note (6); tools/phase_timeline.py reports it as clock_mhz)
+__device__ __forceinline__ void ofx_stamp_rt(unsigned long long* p) {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x78"
+                 : "=&s"(t) : "s"(p));
+}
 __device__ __forceinline__ void ofx_stamp_id(unsigned long long* p) {
     unsigned a, b;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\t"
@@ -171,6 +179,7 @@ constexpr bool TAILMODE = false;
             unsigned long long* sb_ = stamp_base + (size_t)si_ * (NWAVE * 16);                \
             ofx_stamp(sb_ + (i));                                                             \
             if ((i) == 0) ofx_stamp_id(sb_);                                                  \
+            if ((i) == 0) ofx_stamp_rt(sb_);                                                  \
             if ((i) == 12) ++stamp_it;                                                        \
         }                                                                                     \
     } while (0)

@@ -65,7 +65,7 @@ for d in ("sq_1", "sq_2"):
             v, k = counter(d, n)
             sq[n] = v / TRACES
 clock = open(f"{P}/clock_probe.txt").read().strip().split("\n")[-2:] if os.path.exists(f"{P}/clock_probe.txt") else []
-json.dump({"round": rnd, "kernel": "k_fused<0,false>", "traces_per_launch": TRACES,
+json.dump({"round": rnd, "workload": "config1", "kernel": "k_fused<0,false>", "traces_per_launch": TRACES,
            "per_trace": sq,
            "units": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES in units of 4 cycles, summed over the waves of a trace; SQ_INSTS_* wave-instructions",
            "clock_probe": clock}, open(f"{OUT}/{tag}_sq_counters.json", "w"), indent=1)

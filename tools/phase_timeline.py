@@ -88,6 +88,20 @@ def summarise(a):
     return per
 
 
+def clock_mhz(a):
+    """Shader clock inside the kernel: d(s_memtime) / d(s_memrealtime) x 100 MHz between the stamps 0
+    of consecutive traces of a workgroup (slot 15 holds the 100 MHz counter at stamp 0)."""
+    t = a[:, :, 0].astype(np.int64)
+    r = a[:, :, 15].astype(np.int64)
+    dt, dr = t[:, 8:-2] - t[:, 4:-6], r[:, 8:-2] - r[:, 4:-6]      # four traces apart
+    ok = (dr > 0) & (dt > 0) & (t[:, 8:-2] > 0) & (t[:, 4:-6] > 0)
+    if not ok.any():
+        return None
+    c = 100.0 * dt[ok] / dr[ok]
+    return {'mean': float(c.mean()), 'p05': float(np.percentile(c, 5)), 'p95': float(np.percentile(c, 95)),
+            'samples': int(ok.sum()), 'method': 'd(s_memtime) / d(s_memrealtime) x 100 MHz, four traces apart, every workgroup'}
+
+
 def overlap(a):
     """Pairs of workgroups on the same CU (XCC_ID, HW_ID se/sh/cu bits): fraction of the common
     time span in which 2 / 1 / 0 of them are in a register-arithmetic phase."""
@@ -176,6 +190,7 @@ if __name__ == '__main__':
         for k, v in rep['cycles_per_phase_config2'].items():
             print(f'{k:8s} {v:9.0f}')
         print(rep['overlap_2wg'])
+    print('clock in the kernel (MHz):', rep.get('clock_mhz'))
         sys.exit(0)
     if '--config3' in sys.argv:
         # BASELINE configs[3] (three slots, nine searches, windows, bands): the stamps of a trace
@@ -191,9 +206,10 @@ if __name__ == '__main__':
     dest = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline.json'
     a2 = run(n, 2, '/tmp/stamps2.bin')
     a1 = run(n, 1, '/tmp/stamps1.bin')
-    rep = {'cycles_per_phase_2wg_per_cu': summarise(a2), 'cycles_per_phase_1wg_per_cu': summarise(a1),
-           'overlap_2wg': overlap(a2)}
+    rep = {'workload': 'config1', 'cycles_per_phase_2wg_per_cu': summarise(a2), 'cycles_per_phase_1wg_per_cu': summarise(a1),
+           'overlap_2wg': overlap(a2), 'clock_mhz': clock_mhz(a2), 'clock_mhz_1wg_per_cu': clock_mhz(a1)}
     json.dump(rep, open(dest, 'w'), indent=1)
     for k in PH[1:] + ['loop', 'total']:
         print(f"{k:8s} 2wg {rep['cycles_per_phase_2wg_per_cu'][k]:9.0f}   1wg {rep['cycles_per_phase_1wg_per_cu'][k]:9.0f}")
     print(rep['overlap_2wg'])
+    print('clock in the kernel (MHz):', rep.get('clock_mhz'))

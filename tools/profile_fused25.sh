@@ -9,7 +9,7 @@ O=$R/gpurun_out/prof25
 rm -rf $O; mkdir -p $O
 cd $R
 BENCH="python3 bench.py --samples 25000 --config 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $BENCH --steps 5 --warmup 1 --cpu-seconds 3 > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $BENCH --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
 echo "stats done"
 for p in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $p --kernel-trace --output-format csv -d $O/pmc_$p -o run -- $BENCH --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$p.log 2>&1

@@ -14,7 +14,7 @@ O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd $R
 for c in 1 2 3; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -o run -- python3 bench.py --config $c --steps 5 --warmup 1 --cpu-seconds 3 > $O/stats_c$c.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c$c -o run -- python3 bench.py --config $c --steps 5 --warmup 1 --no-cpu-baseline > $O/stats_c$c.log 2>&1
   echo "stats config $c done"
   for p in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $p --kernel-trace --output-format csv -d $O/pmc_${p}_c$c -o run -- python3 bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_${p}_c$c.log 2>&1
