@@ -1308,8 +1308,41 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             __syncthreads();
         }
         TSTAMP(6);                               // bands, interpolation
-        // Per search: every thread's share of the low-frequency chi2 (the last consumers of
-        // VMEM-loaded values), parked per wave in LDS ...
+        // Per search: every thread's share of the low-frequency chi2, parked per wave in LDS.
+        // The thread's bins are FT apart -- k = tt + FT i: bins 0 .. NLOW_MAX-1 from LDS, then (WIDE)
+        // the first chunk of the stash, bins NLOW_MAX .. NLOW_MAX + WCH FT - 1 -- so the phase
+        // exp(-2 pi i k (d + frac) / N) of one search runs along ONE chain: exp(..tt..) and the
+        // uniform step exp(..FT..) from sincospif (integer part of the angle reduced exactly), every
+        // further bin one complex product.  Two sincospif per search and thread instead of one per
+        // bin (six at the 50 kHz cut-off of the reference's example): the terms were 13 k of the 35 k
+        // cycles of a slot's tail in BASELINE configs[3] (profiles/r03_tail_timeline_config3.json).
+        constexpr int WCH = 4;
+        const __amdgpu_buffer_rsrc_t rw_s = make_rsrc(SDX.s, NS_MAX * 8);
+        const __amdgpu_buffer_rsrc_t rw_g = make_rsrc(SDX.g, NS_MAX * 4);
+        [[maybe_unused]] cpx wx[WCH], wsv[WCH];
+        [[maybe_unused]] float wgv[WCH];
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int i = 0; i < WCH; ++i) {
+                const int k = NLOW_MAX + tt + FT * i;
+                wx[i] = buf_ld2(rxw, (k - NLOW_MAX) * 8, 0);
+                wsv[i] = buf_ld2(rw_s, k * 8, 0);
+                wgv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw_g, k * 4, 0, 0));
+            }
+        }
+        auto phase_of = [&](int k, int dl, float frac) {      // exp(-2 pi i k (dl + frac) / N)
+            const int m = (int)(((unsigned)k * (unsigned)dl) & (unsigned)(FN - 1));
+            float sn, cs;
+            sincospif(-2.0f * ((float)m + (float)k * frac) / (float)FN, &sn, &cs);
+            return mk(cs, sn);
+        };
+        auto low_term = [&](int k, cpx ph, float amp, float vx, float vy, cpx S, float g) {
+            const float pr = ph.x * S.x - ph.y * S.y;         // ph S
+            const float pi = ph.x * S.y + ph.y * S.x;
+            const float rr = vx - amp * pr;
+            const float ri = vy - amp * pi;
+            return ((k == 0) ? 1.0f : 2.0f) * g * (rr * rr + ri * ri);
+        };
 #pragma unroll 1
         for (int q = 0; q < SDX.n_search; ++q) {
             const OfxSearchDev& sq = SDX.search[q];
@@ -1321,43 +1354,54 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             ref.chi2 = 0.0f;
             if constexpr (FEAT & 1)
                 if (sq.interp) ref = L.ref[q];
+            cpx ph = phase_of(tt, dl, ref.frac);
+            const cpx step = phase_of(FT, dl, ref.frac);      // uniform
             float low = 0.0f;
 #pragma unroll
             for (int i = 0; i < NLK; ++i) {
                 const int k = tt + FT * i;
                 if (k < sq.nlow) {
                     const cpx x2 = L.xlow[k];
-                    low += ofx_lowchi2_term(k, FN, dl, ref.amp,
-                                            make_float2(0.5f * x2.x, 0.5f * x2.y),
-                                            make_float2(lk_s[i].x, lk_s[i].y), lk_g[i],
-                                            ref.frac);
+                    low += low_term(k, ph, ref.amp, 0.5f * x2.x, 0.5f * x2.y, lk_s[i], lk_g[i]);
+                }
+                ph = cmul(ph, step);
+            }
+            if constexpr (WIDE) {
+                if (sq.nlow > NLOW_MAX) {                             // uniform
+#pragma unroll
+                    for (int i = 0; i < WCH; ++i) {
+                        const int k = NLOW_MAX + tt + FT * i;
+                        if (k < sq.nlow) {
+                            // (entries of the partner blocks are stored conjugated, see MidRsrc)
+                            const float sgn = ((k & 1023) > 512) ? -0.5f : 0.5f;
+                            low += low_term(k, ph, ref.amp, 0.5f * wx[i].x, sgn * wx[i].y, wsv[i], wgv[i]);
+                        }
+                        ph = cmul(ph, step);
+                    }
                 }
             }
             low = ofx_wave_sum(low);
             if (lane_t == 0) L.lowp[q][wave_t] = low;
             if (tt == 0) L.fin[q] = best;
         }
-        TSTAMP(7);                               // low-frequency chi2, bins in LDS
-        // ... WIDE: the bins from NLOW_MAX up, in chunks of WCH per thread read back from the
-        // stash (entries of the partner blocks are conjugated, see MidRsrc) with their table
-        // rows; every search with a cut-off beyond the chunk's first bin adds its share
+        TSTAMP(7);                               // low-frequency chi2: LDS bins and the first stash chunk
+        // ... WIDE, cut-offs beyond the first chunk (> 1536 bins: 58 kHz at 1.25 MHz): the further
+        // chunks of WCH bins per thread, every search with a cut-off beyond the chunk's first bin
+        // adds its share (one sincospif per bin here)
         if constexpr (WIDE) {
-            constexpr int WCH = 4;
-            const __amdgpu_buffer_rsrc_t rw_s = make_rsrc(SDX.s, NS_MAX * 8);
-            const __amdgpu_buffer_rsrc_t rw_g = make_rsrc(SDX.g, NS_MAX * 4);
             int nmax = 0;
 #pragma unroll 1
             for (int q = 0; q < SDX.n_search; ++q) nmax = max(nmax, SDX.search[q].nlow);
 #pragma unroll 1
-            for (int k0 = NLOW_MAX; k0 < nmax; k0 += WCH * FT) {
-                cpx wx[WCH], wsv[WCH];
-                float wg[WCH];
+            for (int k0 = NLOW_MAX + WCH * FT; k0 < nmax; k0 += WCH * FT) {
+                cpx cx[WCH], csv[WCH];
+                float cg[WCH];
 #pragma unroll
                 for (int i = 0; i < WCH; ++i) {
                     const int k = k0 + tt + FT * i;
-                    wx[i] = buf_ld2(rxw, (k - NLOW_MAX) * 8, 0);
-                    wsv[i] = buf_ld2(rw_s, k * 8, 0);
-                    wg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw_g, k * 4, 0, 0));
+                    cx[i] = buf_ld2(rxw, (k - NLOW_MAX) * 8, 0);
+                    csv[i] = buf_ld2(rw_s, k * 8, 0);
+                    cg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rw_g, k * 4, 0, 0));
                 }
 #pragma unroll 1
                 for (int q = 0; q < SDX.n_search; ++q) {
@@ -1378,8 +1422,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                         if (k < sq.nlow) {
                             const float sgn = ((k & 1023) > 512) ? -0.5f : 0.5f;
                             low += ofx_lowchi2_term(k, FN, dl, amp,
-                                                    make_float2(0.5f * wx[i].x, sgn * wx[i].y),
-                                                    make_float2(wsv[i].x, wsv[i].y), wg[i], frac);
+                                                    make_float2(0.5f * cx[i].x, sgn * cx[i].y),
+                                                    make_float2(csv[i].x, csv[i].y), cg[i], frac);
                         }
                     }
                     low = ofx_wave_sum(low);

@@ -345,17 +345,21 @@ __device__ __forceinline__ void t1_apply(cpx (&d)[NV], const T1Anch& an) {
         }
 }
 
-// One term of the low-frequency chi2 (ofx_device.h: ofx_lowchi2_term) with the trace length
-// as a compile-time constant: k d < 2^31 for k < 1250, and the remainder by 25000 is a
-// multiply-high.
-__device__ __forceinline__ float lowchi2_term(int k, int dl, float amp, cpx x2, cpx S, float g,
-                                              float frac) {
+// Low-frequency chi2 (ofx_device.h: ofx_lowchi2_term) with the trace length as a compile-time
+// constant.  The bins of a thread are GT apart, so the phase exp(-2 pi i k (d + frac) / N) of a search
+// runs along a chain: lowchi2_phase(tt) and the uniform step lowchi2_phase(GT) from sincospif (integer
+// part of the angle reduced exactly: k d < 2^31 for k < 1250, the remainder by GN a multiply-high),
+// every further bin one complex product -- two sincospif per search and thread instead of five.
+__device__ __forceinline__ cpx lowchi2_phase(int k, int dl, float frac) {
     int m = (k * dl) % GN;
     m = m < 0 ? m + GN : m;
     float sn, cs;
     sincospif(-2.0f * ((float)m + (float)k * frac) / (float)GN, &sn, &cs);
-    const float pr = cs * S.x - sn * S.y;
-    const float pi = cs * S.y + sn * S.x;
+    return mk(cs, sn);
+}
+__device__ __forceinline__ float lowchi2_term(int k, cpx ph, float amp, cpx x2, cpx S, float g) {
+    const float pr = ph.x * S.x - ph.y * S.y;
+    const float pi = ph.x * S.y + ph.y * S.x;
     const float rr = 0.5f * x2.x - amp * pr;
     const float ri = 0.5f * x2.y - amp * pi;
     const float w = (k == 0) ? 1.0f : 2.0f;
@@ -1158,11 +1162,14 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                 if constexpr (FEAT & 1)
                     if (sq.interp) ref = L.ref[q];
                 float low = 0.0f;
+                cpx ph = lowchi2_phase(act_t ? tt : 0, dl, ref.frac);
+                const cpx step = lowchi2_phase(GT, dl, ref.frac);        // uniform
 #pragma unroll
                 for (int i = 0; i < NLK; ++i) {
                     const int k = tt + GT * i;
                     if (act_t && k < sq.nlow)
-                        low += lowchi2_term(k, dl, ref.amp, L.xlow[k], lk_s[i], lk_g[i], ref.frac);
+                        low += lowchi2_term(k, ph, ref.amp, L.xlow[k], lk_s[i], lk_g[i]);
+                    ph = cmul(ph, step);
                 }
                 low = ofx_wave_sum(low);
                 if (lane_t == 0) L.lowp[q][wave_t] = low;
