@@ -337,8 +337,10 @@ def main():
         raise SystemExit("--stream-events runs the config 1 workload")
     # v = A roll(template, d) + coloured noise drawn from J; A log-uniform in
     # [3, 300] sigma_A for half of the events, d uniform in [-2000, 2000]; keyed by (seed, index)
+    # (streaming: white noise of the PSD's median level -- the generator then costs one HBM write
+    # per trace, like an ingest would; resident shards keep the coloured noise of SURVEY.md 8d)
     gen = SynthSource(N_SAMPLES, tmpl, psd, FS, 3 * ft.ampres, 300 * ft.ampres, 0.5, 2000,
-                      seed=2026, device=local_rank)
+                      seed=2026, device=local_rank, white=streaming)
 
     # events per GPU, capped by free HBM (input + output + slack)
     B = (args.chunk * 2 if streaming else args.traces // C)
@@ -476,7 +478,8 @@ def main():
             "config": {"workload": f"{n_local} events/GPU x {C} channel(s) x {N_SAMPLES} samples, "
                                    + what
                                    + (f"; streamed in chunks of {args.chunk} events generated "
-                                      f"on a producer stream (configs[4] rehearsal)"
+                                      f"(white noise + pulse, k_synth) on a producer stream "
+                                      f"(configs[4] rehearsal)"
                                       if streaming else ""),
                        "bench_config": args.config, "engine": "+".join(engines),
                        "events_per_gpu": n_local, "traces_per_gpu": n_local * C,

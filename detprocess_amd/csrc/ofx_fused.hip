@@ -1774,10 +1774,16 @@ static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlo
                        const FusedTabs& tabs, const float* d_traces, const uint8_t* d_valid,
                        long long n, float* d_out, hipStream_t st, const FusedSlotArg* d_slots,
                        int nslots, int nstash) {
-#ifdef OFX_QUICK      // development builds: only one variant is compiled (-DOFX_QUICK=<feat>, 0 = headline)
-    if (feat == (OFX_QUICK + 0) && !MULTI)
-        return launch<OFX_QUICK + 0, false>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
-                                            nslots, nstash);
+#ifdef OFX_QUICK      // development builds: only one variant is compiled (-DOFX_QUICK=<feat>, 0 = headline;
+                      // -DOFX_QUICK_MULTI: its several-slots form)
+#ifdef OFX_QUICK_MULTI
+    constexpr bool QM = true;
+#else
+    constexpr bool QM = false;
+#endif
+    if (feat == (OFX_QUICK + 0) && MULTI == QM)
+        return launch<OFX_QUICK + 0, QM>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
+                                         nslots, nstash);
     ofx_set_error("OFX_QUICK build: only the FEAT = %d single-slot kernel exists", OFX_QUICK + 0);
     return OFX_ERR_UNSUPPORTED;
 #else

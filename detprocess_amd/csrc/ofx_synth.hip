@@ -37,6 +37,29 @@ __device__ __forceinline__ float u01(uint32_t x) {      // (0,1]
     return ((float)(x >> 8) + 1.0f) * (1.0f / 16777216.0f);
 }
 
+// White noise + pulse, the HBM-write-bound source of the streaming form of the bench (BASELINE
+// configs[4] rehearsal, detprocess_amd.dist.run_sharded): one 128 KiB write per trace and ~15 VALU
+// instructions per sample -- a 32-bit counter hash instead of Philox, Box-Muller on the hardware
+// log2 / sqrt / sin / cos (1 ulp-ish: a bench source, not a statistics library), so that it can share
+// the chip with the fused kernel without becoming the slower of the two (the coloured generator below
+// moves ~5x the trace bytes and runs at 1.9 M traces/s; it stays the source of the tests).
+// Counter-based: sample n of trace gid depends on (seed, gid, n) only.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {      // "lowbias32" (Wellons)
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float2 box_muller_fast(uint32_t ur, uint32_t ua) {
+    // radius from a 24-bit uniform in (0, 1], angle (in turns) from the top bits of ua (16 used)
+    const float u = ((float)(ur >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(u));   // sqrt(-2 ln u)
+    const float t = (float)(ua >> 8) * (1.0f / 16777216.0f);
+    return make_float2(r * __builtin_amdgcn_cosf(t), r * __builtin_amdgcn_sinf(t));
+}
+
 // one block per trace, 256 threads, 4 samples per thread per iteration
 __global__ __launch_bounds__(256) void k_synth(float* __restrict__ traces,
                                                float* __restrict__ truth, long long first,
@@ -58,28 +81,22 @@ __global__ __launch_bounds__(256) void k_synth(float* __restrict__ traces,
         truth[2 * b] = amp;
         truth[2 * b + 1] = (float)delay;
     }
+    const uint32_t key = r[3];                       // per-trace key of the sample hash (uniform)
     float* t = traces + (size_t)b * N;
     for (int n4 = threadIdx.x; n4 < N / 4; n4 += 256) {
-        philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)n4, 1u, k0, k1, r);
-        float z[4];
-        {
-            const float r0 = sqrtf(-2.0f * logf(u01(r[0])));
-            float s, c;
-            sincospif(2.0f * u01(r[1]), &s, &c);
-            z[0] = r0 * c; z[1] = r0 * s;
-            const float r1 = sqrtf(-2.0f * logf(u01(r[2])));
-            sincospif(2.0f * u01(r[3]), &s, &c);
-            z[2] = r1 * c; z[3] = r1 * s;
-        }
+        const uint32_t c = key + 3u * (uint32_t)n4;
+        const uint32_t h0 = hash32(c), h1 = hash32(c + 1u), h2 = hash32(c + 2u);
+        const float2 za = box_muller_fast(h0, h2 << 16), zb = box_muller_fast(h1, h2 & 0xffff0000u);
+        const float z[4] = {za.x, za.y, zb.x, zb.y};
         float4 v;
         float* pv = &v.x;
+        int src = 4 * n4 - delay;
+        src = src < 0 ? src + N : src;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = 4 * n4 + j;
-            int src = n - delay;
-            if (src < 0) src += N;
-            if (src >= N) src -= N;
-            pv[j] = fmaf(amp, tmpl[src], sigma * z[j]);
+            int sj = src + j;
+            sj = sj >= N ? sj - N : sj;
+            pv[j] = fmaf(amp, tmpl[sj], sigma * z[j]);
         }
         *reinterpret_cast<float4*>(t + 4 * n4) = v;
     }

@@ -303,8 +303,14 @@ class SynthSource:
     (``detprocess_amd.dist.run_sharded``)."""
 
     def __init__(self, n_samples, template, psd, fs, amp_lo, amp_hi, pulse_fraction=0.5,
-                 max_delay=2000, seed=0, device=0):
+                 max_delay=2000, seed=0, device=0, white=False):
+        """white=True: white Gaussian noise of the PSD's median level instead of noise coloured by
+        J (ofx_synth_traces: one HBM write per trace and nothing else -- the source of the streamed
+        form of the bench, which must not be slower than the path it feeds; the coloured form,
+        k_spectrum -> rocFFT C2R -> k_add_pulse, moves ~5x the trace bytes)."""
         torch = _torch()
+        self.white = bool(white)
+        self._sigma = float(np.sqrt(np.median(np.asarray(psd, dtype=np.float64)) * float(fs)))
         self._lib = _lib.load()
         self.n_samples = int(n_samples)
         self.device = torch.device("cuda", device)
@@ -327,6 +333,11 @@ class SynthSource:
                              "least hi - lo events")
         stream = torch.cuda.current_stream(self.device).cuda_stream
         a_lo, a_hi, frac, dmax, seed = self._args
+        if self.white:
+            _lib.check(self._lib.ofx_synth_traces(
+                buf.data_ptr(), None, n, int(lo), self.n_samples, self._t.data_ptr(), self._sigma,
+                a_lo, a_hi, frac, dmax, seed, C.c_void_p(stream)), "ofx_synth_traces")
+            return
         _lib.check(self._lib.ofx_synth_traces_psd(
             buf.data_ptr(), None, n, int(lo), self.n_samples, self._t.data_ptr(),
             self._namp.data_ptr(), a_lo, a_hi, frac, dmax, seed, C.c_void_p(stream)),

@@ -536,6 +536,48 @@ def test_coloured_noise_generator_matches_its_psd():
     assert float((((r[:, 0] - tr[:, 0]) / ft.ampres).abs() < 5).float().mean()) > 0.995
 
 
+def test_white_noise_generator_statistics_and_keys():
+    """ofx_synth_traces (k_synth: counter hash + Box-Muller on the hardware log2 / sqrt / sin / cos; the
+    source of the streamed bench): samples are N(0, sigma^2) to the accuracy 16 M of them can show,
+    neighbouring samples / traces are uncorrelated, a shard equals the same rows of the whole run
+    (keyed by seed and global index), another seed gives other traces, and SynthSource(white=True)
+    writes exactly these traces."""
+    import torch
+    from detprocess_amd import SynthSource, synth_traces
+    n, pre, B = 32768, 16384, 512
+    tmpl = synth.make_template(n, pre, FS)
+    sigma = 3.0e-9
+    x, truth = synth_traces(B, n, tmpl, sigma, 1e-8, 1e-7, 0.0, 2000, seed=11)
+    assert float(truth[:, 0].abs().max()) == 0.0
+    z = (x.double() / sigma)
+    m = z.numel()
+    assert abs(float(z.mean())) < 5.0 / np.sqrt(m)
+    assert abs(float(z.var()) - 1.0) < 5.0 * np.sqrt(2.0 / m)
+    assert abs(float((z ** 3).mean())) < 5.0 * np.sqrt(15.0 / m)            # skewness
+    assert abs(float((z ** 4).mean()) - 3.0) < 5.0 * np.sqrt(96.0 / m)      # kurtosis
+    assert abs(float((z.abs() > 3.0).double().mean()) - 2.6998e-3) < 5.0 * np.sqrt(2.7e-3 / m)
+    assert float(z.abs().max()) > 4.5                                       # the tails are there
+    for lag in (1, 2, 3, 4, 5, 256, 1024):                                  # within a trace
+        assert abs(float((z[:, lag:] * z[:, :-lag]).mean())) < 5.0 / np.sqrt(m)
+    assert abs(float((z[1:] * z[:-1]).mean())) < 5.0 / np.sqrt(m)           # across traces
+    y, _ = synth_traces(100, n, tmpl, sigma, 1e-8, 1e-7, 0.0, 2000, seed=11, first_index=300)
+    assert torch.equal(y, x[300:400])
+    w, _ = synth_traces(4, n, tmpl, sigma, 1e-8, 1e-7, 0.0, 2000, seed=12)
+    assert not torch.equal(w, x[:4])
+    # with pulses: trace = amp * roll(template, delay) + the same noise
+    p, tr = synth_traces(64, n, tmpl, sigma, 1e-8, 1e-7, 1.0, 2000, seed=11)
+    t64 = torch.as_tensor(tmpl, device="cuda:0")
+    for i in (0, 17, 63):
+        want = tr[i, 0].double() * torch.roll(t64, int(tr[i, 1])) + x[i].double()
+        assert float((p[i].double() - want).abs().max()) < 1e-6 * float(tr[i, 0])
+    psd = np.full(n, sigma ** 2 / FS)
+    src = SynthSource(n, tmpl, psd, FS, 1e-8, 1e-7, 0.0, 2000, seed=11, white=True)
+    buf = torch.empty((64, n), dtype=torch.float32, device="cuda:0")
+    src.fill(100, 164, buf)
+    torch.cuda.synchronize()
+    assert torch.allclose(buf, x[100:164], rtol=1e-6, atol=0.0)
+
+
 @pytest.mark.parametrize("n", [24000, 25000, 30000])
 def test_lds_three_slots_at_other_lengths(n):
     """Several template tags on the LDS engine at lengths that run its 1024-thread builds
