@@ -8,7 +8,7 @@ import pytest
 
 from detprocess_amd import build_filter, synth
 from oracle import of1x1 as orc
-from util import check_search
+from util import check_search, combine_fp32
 
 pytestmark = pytest.mark.gpu
 FS = 1.25e6
@@ -335,12 +335,9 @@ def test_channel_algebra_on_load(engine):
     for idx, wts in (([0, 2], [0.9, 1.1]), ([1, 0], [1.0, -1.0]), ([2], [1.0])):
         plan.set_channels(3, idx, wts)
         out = plan.process(torch.as_tensor(ev, device="cuda:0")).cpu().numpy().astype(np.float64)
-        comb = sum(np.float64(w) * ev[:, c, :].astype(np.float64) for c, w in zip(idx, wts))
+        comb = combine_fp32(ev, idx, wts)                 # the trace the device forms, bit for bit
         ref = orc.process_events(filt, comb, "unconstrained")
-        o = plan.search_offset(0, sid)
-        assert np.array_equal(out[:, o + 7].astype(int), ref["index"])
-        assert np.allclose(out[:, o + 0], ref["amp"], rtol=3e-5, atol=2e-4 * ft.ampres)
-        assert np.allclose(out[:, o + 4], ref["chi2nopulse"], rtol=3e-5)
+        check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, f"{engine} {idx} {wts}")
         t = plan.tdwindow_offset(wid)
         assert np.allclose(out[:, t + 0], orc.baseline(comb, 100, 20000), rtol=1e-4,
                            atol=1e-6 * np.abs(comb).max())
@@ -534,6 +531,47 @@ def test_coloured_noise_generator_matches_its_psd():
     r = plan2.process(z)
     assert float(((r[:, 7] - pre - tr[:, 1]).abs() <= 3).float().mean()) > 0.99
     assert float((((r[:, 0] - tr[:, 0]) / ft.ampres).abs() < 5).float().mean()) > 0.995
+
+
+def _lag_amps(filt, x64):
+    return np.stack([orc.signal_products(filt, t)[2] for t in x64])
+
+
+@pytest.mark.parametrize("engine", ["rocfft", "lds"])
+def test_classified_near_tie_and_flat_top_of_the_round_2_fuzz(engine):
+    """The two loose ends of round 2's randomised runs, as tests with the rule that classifies them
+    (tests/util.py; the fp64 side of both is pinned in tests/test_oracle_kat.py):
+    (i) seed 77 case 28 -- 24000 samples, muon filter: the engines report rolled bin 3381, the oracle
+        3382; the fp64 amplitudes there differ by 4.6e-8, a near tie (TIE_RTOL = 1e-6 in A^2);
+    (ii) seed 101 case 113 -- 500 samples, glitch filter on a pulse, interpolated: the vertex of a flat
+        top (three amplitudes equal to 2.7e-4) moves by 1e-3 sample with the fp32 amplitudes; the
+        tolerance follows the conditioning of the parabola (t0_interp_tol_samples: 7e-3 here)."""
+    import torch
+    from detprocess_amd import OFPlan
+    from test_oracle_kat import flat_top_case, near_tie_case
+    n, pre, psd, tm, x64 = near_tie_case()
+    ft, filt = build_filter(tm, psd, FS, pre), orc.OFFilter(tm, psd, FS, pre)
+    plan = OFPlan(n, pre, FS, max_batch=16, device=0, engine=engine)
+    plan.set_filter(0, ft)
+    sid = plan.add_search(0, "delay")
+    out = plan.process(torch.as_tensor(x64.astype(np.float32), device="cuda:0")).cpu().numpy().astype(np.float64)
+    ref = orc.process_events(filt, x64, "unconstrained")
+    ties = check_search(out, plan.search_offset(0, sid), ref, "", ft.ampres, FS, f"{engine} near tie",
+                        lag_amps=_lag_amps(filt, x64))
+    assert ties <= 1                      # event 2, if the engine lands on 3381
+    plan.close()
+    n, pre, psd, tg, x64 = flat_top_case()
+    ft, filt = build_filter(tg, psd, FS, pre), orc.OFFilter(tg, psd, FS, pre)
+    plan = OFPlan(n, pre, FS, max_batch=64, device=0, engine=engine)
+    plan.set_filter(0, ft)
+    sid = plan.add_search(0, "delay", interpolate=True)
+    out = plan.process(torch.as_tensor(x64.astype(np.float32), device="cuda:0")).cpu().numpy().astype(np.float64)
+    ref = orc.process_events(filt, x64, "unconstrained", interpolate=True)
+    keep = np.abs(ref["amp"]) > 50 * ft.ampres            # clear pulses (the fuzz's own selection)
+    assert keep[8]
+    check_search(out[keep], plan.search_offset(0, sid), {k: np.asarray(v)[keep] for k, v in ref.items()}, "",
+                 ft.ampres, FS, f"{engine} flat top", interpolated=True, lag_amps=_lag_amps(filt, x64[keep]))
+    plan.close()
 
 
 def test_white_noise_generator_statistics_and_keys():
@@ -756,22 +794,17 @@ def test_every_instantiation_of_the_fused_kernel_vs_oracle(feat, nslots):
     ev = ev.reshape(B, nch, n).astype(np.float32)
     if feat & 4:
         plan.set_channels(2, [1, 0], [1.0, -0.5])
-        x64 = ev[:, 1].astype(np.float64) - 0.5 * ev[:, 0].astype(np.float64)
+        x64 = combine_fp32(ev, [1, 0], [1.0, -0.5])       # the trace the device forms, bit for bit
         out = plan.process(torch.as_tensor(ev, device="cuda:0")).cpu().numpy().astype(np.float64)
     else:
         x64 = ev[:, 0].astype(np.float64)
         out = plan.process(torch.as_tensor(ev[:, 0], device="cuda:0")).cpu().numpy().astype(np.float64)
     assert plan.engine == "fused"
-    tol = 3e-5 if feat & 4 else 1e-5                  # (the combined trace is rounded to fp32 on the device)
     for s, (ft, filt) in enumerate(zip(fts, filts)):
         for mode, sid in ids[s]:
             kw = dict(window_min_index=pre - 400, window_max_index=pre + 400) if mode == "constrained" else {}
             r = orc.process_events(filt, x64, mode, lowchi2_fcutoff=fc, **kw)
-            o = plan.search_offset(s, sid)
-            assert np.array_equal(out[:, o + 7].astype(int), r["index"]), (feat, nslots, s, mode)
-            assert np.all(np.abs(out[:, o] - r["amp"]) <= tol * np.abs(r["amp"]) + 2e-4 * ft.ampres), (feat, nslots, s, mode)
-            assert np.all(np.abs(out[:, o + 2] - r["chi2"]) <= tol * r["chi2"] + 4e-6 * out[:, o + 4]), (feat, nslots, s, mode)
-            assert np.all(np.abs(out[:, o + 3] - r["lowchi2"]) <= tol * r["lowchi2"] + 4e-6 * out[:, o + 4]), (feat, nslots, s, mode)
+            check_search(out, plan.search_offset(s, sid), r, "", ft.ampres, FS, f"k_fused<{feat}> x{nslots} slot {s} {mode}")
     sc = np.abs(x64).max()
     for (a, b), w in zip(wins, wid):
         t_ = plan.tdwindow_offset(w)

@@ -200,3 +200,73 @@ def test_integralnorm_and_interpolate_are_plumbed():
     r1 = orc.of1x1_withdelay(f, v, interpolate=True)
     assert abs(r1["t0"] - r0["t0"]) <= 0.5 / FS + 1e-12
     assert r1["chi2"] <= r0["chi2"] + 1e-9
+
+
+def near_tie_case():
+    """The t0-bin flip of the general fuzz (tools/fuzz_engines.py, seed 77, case 28; round 2's
+    gpurun_out/r2_fuzz_gen3.log): 24000 samples, pretrigger 3375, traces of seed 448383790, the muon
+    template, event 2, SNR 117 -- both the ROCFFT and the LDS engine report bin 3381, the oracle 3382."""
+    n, pre = 24000, 3375
+    psd = synth.make_psd(n, FS)
+    tp = synth.make_template(n, pre, FS, "pulse")
+    from detprocess_amd import build_filter
+    x, _, _ = synth.make_traces(5, tp, psd, FS, build_filter(tp, psd, FS, pre).ampres, seed=448383790,
+                                max_delay=n // 16)
+    x64 = x.astype(np.float32).astype(np.float64)
+    tm = synth.make_template(n, pre, FS, "muon")
+    return n, pre, psd, tm, x64
+
+
+def test_near_tie_of_the_fuzz_is_a_tie_in_fp64():
+    """Classification of that flip: in fp64 the amplitudes at rolled bins 3381 and 3382 differ by 4.6e-8
+    relative (chi2 by 1.3e-8 of chi2_0) -- below one fp32 ulp, an order of magnitude below the fp32
+    transform's error: a near tie, not a defect.  The rule (tests/util.py: TIE_RTOL = 1e-6 in A^2)
+    accepts it; a clear winner two bins away would not pass."""
+    import util
+    n, pre, psd, tm, x64 = near_tie_case()
+    filt = orc.OFFilter(tm, psd, FS, pre)
+    V, chi0, amps_r, chi2_r = orc.signal_products(filt, x64[2])
+    assert int(np.argmin(chi2_r)) == 3382
+    rel = abs(amps_r[3381] ** 2 - amps_r[3382] ** 2) / amps_r[3382] ** 2
+    assert rel < 2e-7 < util.TIE_RTOL
+    assert abs(chi2_r[3381] - chi2_r[3382]) < 2e-8 * chi0
+    assert abs(amps_r[3382]) / filt.ampres > 100
+    assert abs(amps_r[3380] ** 2 - amps_r[3382] ** 2) / amps_r[3382] ** 2 > 100 * util.TIE_RTOL
+
+
+def flat_top_case():
+    """The interpolated fit of round 2's soak (general fuzz seed 101, case 113): 500 samples, pretrigger
+    415, traces of seed 482110150 (pulse template), fitted with the GLITCH filter; event 8, SNR 154."""
+    n, pre = 500, 415
+    psd = synth.make_psd(n, FS)
+    tp = synth.make_template(n, pre, FS, "pulse")
+    x, _, _ = synth.make_traces(68, tp, psd, FS, build_filter(tp, psd, FS, pre).ampres, seed=482110150,
+                                max_delay=max(1, n // 16))
+    return n, pre, psd, synth.make_template(n, pre, FS, "glitch"), x.astype(np.float32).astype(np.float64)
+
+
+def test_interpolated_t0_tolerance_follows_the_conditioning_of_the_parabola():
+    """The 1.02e-3 sample of that case is the fp32 amplitude error times the condition number of the
+    vertex, not a defect: the three amplitudes agree to 2.7e-4, a relative change of 1e-6 of the middle
+    one moves the vertex by 3e-3 sample, and util.t0_interp_tol_samples allows 7e-3; a pulse fitted with
+    its own template is allowed 1.4e-5."""
+    import util
+    n, pre, psd, tg, x64 = flat_top_case()
+    filt = orc.OFFilter(tg, psd, FS, pre)
+    V, chi0, a, chi2_r = orc.signal_products(filt, x64[8])
+    i = int(np.argmin(chi2_r))
+    assert i == 446 and abs(a[i]) / filt.ampres > 150
+    assert abs(a[i - 1] / a[i] - 1) < 3e-4 and abs(a[i + 1] / a[i] - 1) < 3e-4
+
+    def vertex(am, a0, ap):
+        return 0.5 * (ap - am) * (ap + am) / ((a0 - am) * (a0 + am) + (a0 - ap) * (a0 + ap))
+    x0 = vertex(a[i - 1], a[i], a[i + 1])
+    moved = abs(vertex(a[i - 1], a[i] * (1 + 1e-6), a[i + 1]) - x0)
+    assert 2e-3 < moved < 5e-3
+    tol = util.t0_interp_tol_samples(a[i - 1], a[i], a[i + 1], np.abs(a).max())
+    assert moved < tol < 1e-2 and tol > 1.02e-3
+    # matched template: the same event through the pulse filter
+    fp = orc.OFFilter(synth.make_template(n, pre, FS, "pulse"), psd, FS, pre)
+    V, chi0, b, c2 = orc.signal_products(fp, x64[8])
+    j = int(np.argmin(c2))
+    assert util.t0_interp_tol_samples(b[j - 1], b[j], b[j + 1], np.abs(b).max()) < 5e-5
