@@ -32,21 +32,26 @@ OBSOLETE_KEYS = {          # config.py:71-79
 
 class _UniqueKeyLoader(SafeLoader):
     """PyYAML silently keeps the last duplicate key; the reference refuses
-    (config.py:666-684).  The stock constructor builds the mapping; a mapping that came out
-    with fewer keys than the node has entries had a duplicate, which is then named."""
+    (config.py:666-684).  Duplicates are looked for on the key nodes as written, BEFORE the stock
+    constructor expands merge keys ('<<: *base' followed by an overriding key is legal YAML and
+    not a duplicate); the mapping itself is then built by the stock constructor."""
 
     def construct_mapping(self, node, deep=False):
-        mapping = super().construct_mapping(node, deep=deep)
-        if len(mapping) != len(node.value):
-            seen = set()
-            for key_node, _ in node.value:
-                key = self.construct_object(key_node, deep=True)
-                if key in seen:
-                    raise ValueError(f'ERROR: Duplicate key "{key}" found in the yaml file for '
-                                     f'same channel and algorithm. This is not allowed to '
-                                     f'avoid unwanted configuration!')
-                seen.add(key)
-        return mapping
+        seen = set()
+        for key_node, _ in node.value:
+            if key_node.tag == "tag:yaml.org,2002:merge":
+                continue
+            key = self.construct_object(key_node, deep=True)
+            try:
+                dup = key in seen
+            except TypeError:                  # unhashable key: left to the stock constructor
+                continue
+            if dup:
+                raise ValueError(f'ERROR: Duplicate key "{key}" found in the yaml file for '
+                                 f'same channel and algorithm. This is not allowed to '
+                                 f'avoid unwanted configuration!')
+            seen.add(key)
+        return super().construct_mapping(node, deep=deep)
 
 
 def _rename_keys(d, old, new):

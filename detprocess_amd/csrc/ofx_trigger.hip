@@ -668,6 +668,11 @@ extern "C" int ofx_trigger_above(ofx_trigger* t, double chi2_threshold, long lon
         ofx_set_error("ofx_trigger_above: bad argument");
         return OFX_ERR_ARG;
     }
+    if (t->n > 0x7fffffffLL) {       // hipcub::DeviceSelect takes an int count
+        ofx_set_error("ofx_trigger_above: stream of %lld samples (the dynamic-window search handles up "
+                      "to 2^31 - 1 per call: split the stream)", (long long)t->n);
+        return OFX_ERR_ARG;
+    }
     OFX_HIP(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream;
     const long long n = t->n;
@@ -778,9 +783,18 @@ extern "C" int ofx_trigger_residual_subtract(ofx_trigger* t, const long long* tr
 
 extern "C" int ofx_trigger_residual_restore(ofx_trigger* t, float* residual_delta_chi2, int mem,
                                             void* stream) {
-    if (!t || t->n == 0 || !t->saved) {
-        ofx_set_error("ofx_trigger_residual_restore: nothing saved");
+    if (!t || t->n == 0) {
+        ofx_set_error("ofx_trigger_residual_restore: no trace");
         return OFX_ERR_STATE;
+    }
+    if (!t->saved) {
+        // nothing to put back (the subtract call failed before it saved the trace): the first-pass
+        // trace is still in place; a caller that asked for the residual trace gets an error
+        if (residual_delta_chi2) {
+            ofx_set_error("ofx_trigger_residual_restore: nothing saved");
+            return OFX_ERR_STATE;
+        }
+        return OFX_OK;
     }
     OFX_HIP(hipSetDevice(t->device));
     hipStream_t st = (hipStream_t)stream;

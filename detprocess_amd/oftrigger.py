@@ -363,16 +363,23 @@ class OptimumFilterTrigger:
             self._pulse_set = True
         keep = np.asarray([ti for ti in original_triggers
                            if not self._saturated(int(ti), positive_pulses, sat)], dtype=np.int64)
-        _lib.check(self._lib.ofx_trigger_residual_subtract(
-            self._h, keep.ctypes.data if len(keep) else None, len(keep), None),
-            "ofx_trigger_residual_subtract")
         res = np.empty(self._n, dtype=np.float32) if return_trigger_data else None
         try:
+            # (inside the try: a failure after the first-pass trace was saved, or half-way through the
+            # subtraction, must still put it back)
+            _lib.check(self._lib.ofx_trigger_residual_subtract(
+                self._h, keep.ctypes.data if len(keep) else None, len(keep), None),
+                "ofx_trigger_residual_subtract")
             self.find_triggers_once(thresh, pileup_window_msec, pileup_window_samples, dynamic,
                                     dynamic_threshold_function)
             new_triggers = list(self._trigger_data[name]["trigger_index"])
             new_trigger_data = copy.deepcopy(self._trigger_data)
-        finally:        # whatever happens, the first-pass trace goes back (oftrigger.py:824-828)
+        except BaseException:
+            # the first-pass trace goes back whatever happened (oftrigger.py:824-828); the residual
+            # trace is not asked for on this path, so a subtract that failed before saving is fine
+            self._lib.ofx_trigger_residual_restore(self._h, None, _lib.MEM_HOST, None)
+            raise
+        else:
             _lib.check(self._lib.ofx_trigger_residual_restore(
                 self._h, res.ctypes.data if res is not None else None, _lib.MEM_HOST, None),
                 "ofx_trigger_residual_restore")

@@ -29,7 +29,19 @@ OF_ALGORITHMS = {
                                     "ampres", "timeres")),
 }
 TD_ALGORITHMS = ("baseline", "integral", "maximum", "minimum")
-FUSED_MAX_BAND_BIN = 4096      # bins the FUSED engine keeps for psd_amp / lowchi2 (LDS + stash)
+# Low-frequency bins (psd_amp bands, lowchi2 cut-offs) an engine keeps per trace: the FUSED kernels by
+# trace length (32768: 512 in LDS + a stash up to 4096; 25000 / 20000 / 12500: 2.5 x 25 R1 bins in
+# LDS), the LDS engine 1024.  A plan that needs more is compiled for the ROCFFT engine at once, instead
+# of failing (engine='fused') or retrying engine after engine on every call (engine='auto').
+FUSED_MAX_BIN = {32768: 4096, 25000: 1250, 20000: 1000, 12500: 625}
+LDS_MAX_BIN = 1024
+FUSED_MAX_BAND_BIN = FUSED_MAX_BIN[32768]      # (the 32768-sample figure, kept for callers)
+
+
+def engine_bin_limit(n_samples):
+    """Bins the non-ROCFFT engine that would carry an `n_samples` plan keeps for bands / lowchi2."""
+    return FUSED_MAX_BIN.get(int(n_samples), LDS_MAX_BIN)
+
 # algorithms whose base name contains one of these get an OFBase in the reference
 # (processing_data.py:93-97); the ones not implemented here raise explicitly
 OF_BASE_PREFIXES = ["of1x1", "of1x2x2", "of1x3x3", "ofnxm", "ofnxmx2", "psd_amp",
@@ -214,14 +226,18 @@ class FeatureProcessing:
                 # lowest bins); otherwise the general ROCFFT engine carries them
                 engine = self._engine
                 bands = [x for x in pending if x[0] == "band"]
-                if bands and engine != "rocfft":
+                if engine != "rocfft":
                     has_of = any(x[0] == "of" for x in pending)
                     kmax = 0
                     for x in bands:
                         rng, _ = utils.cleanup_freq_ranges(x[4]["f_lims"])
                         kmax = max([kmax] + [hi for _, hi in utils.get_bin_ranges(rng, n_samples,
                                                                                   self._fs)])
-                    if not has_of or kmax > FUSED_MAX_BAND_BIN:
+                    for x in pending:                 # bins |f| <= lowchi2_fcutoff of the OF algorithms
+                        if x[0] == "of":
+                            fcut = float(x[4].get("lowchi2_fcutoff", 10000))
+                            kmax = max(kmax, int(np.floor(fcut * n_samples / self._fs)) + 1)
+                    if (bands and not has_of) or kmax > engine_bin_limit(n_samples):
                         engine = "rocfft"
                 plan = OFPlan(n_samples, nb_pre_plan, self._fs, max_batch=self._max_batch,
                               device=self._device, engine=engine)

@@ -130,3 +130,41 @@ def test_device_resident_rows_equal_the_dataframe():
             assert np.array_equal(m[:, off], np.asarray(df[name])), name
             seen += 1
     assert seen == len(df.columns)
+
+
+@pytest.mark.parametrize("n,fcut,want", [(25000, 100000.0, "rocfft"), (25000, 50000.0, "fused"),
+                                         (12500, 50000.0, "fused"), (12500, 100000.0, "rocfft"),
+                                         (32768, 150000.0, "fused"), (32768, 200000.0, "rocfft")])
+def test_plans_beyond_the_stashed_bins_are_compiled_for_rocfft(n, fcut, want, monkeypatch):
+    """A lowchi2 cut-off (or psd_amp band) beyond the bins the fused kernel of that trace length keeps
+    (32768: 4096, 25000: 1250, 12500: 625; process.FUSED_MAX_BIN) picks the ROCFFT engine when the plan
+    is compiled -- with engine='fused' as with 'auto' -- instead of failing on every call; the result
+    equals the oracle either way."""
+    import bench
+    from detprocess_amd import FeatureProcessing
+    from detprocess_amd.process import engine_bin_limit
+    from oracle import of1x1 as orc
+    from util import check_search
+    monkeypatch.setattr(bench, "N_SAMPLES", n)
+    pre, B = n // 2, 6
+    nbins = int(np.floor(fcut * n / FS)) + 1
+    assert (nbins > engine_bin_limit(n)) == (want == "rocfft")
+    fd = bench.filter_data3(pre)
+    yaml = ("chA:\n    of1x1_unconstrained:\n        run: True\n        template_tag: pulse\n"
+            f"        csd_tag: default\n        lowchi2_fcutoff: {fcut}\n")
+    J = synth.make_psd(n, FS)
+    tp = synth.make_template(n, pre, FS, "pulse")
+    filt = orc.OFFilter(tp, J, FS, pre)
+    x, _, _ = synth.make_traces(B, tp, J, FS, filt.ampres, seed=9, max_delay=300)
+    ev = np.zeros((B, 4, n), dtype=np.float32)
+    ev[:, 0] = x
+    for engine in ("fused", "auto"):
+        fp = FeatureProcessing(yaml, fd, bench.CHANNELS3, FS, engine=engine)
+        df = fp.process(ev)
+        assert {p.engine for p in fp.plans().values()} == {want}, engine
+        ref = orc.process_events(filt, ev[:, 0].astype(np.float64), "unconstrained", fcut)
+        out = np.zeros((B, 8))
+        for j, k in enumerate(("amp", "t0", "chi2", "lowchi2")):
+            out[:, j] = df[f"{k}_of1x1_unconstrained_chA"]
+        out[:, 4], out[:, 5], out[:, 6], out[:, 7] = ref["chi2nopulse"], ref["ampres"], ref["timeres"], ref["index"]
+        check_search(out, 0, ref, "", filt.ampres, FS, f"{n} / {fcut} / {engine}", lowchi2_fcutoff=fcut)

@@ -105,7 +105,7 @@ def test_two_rank_gloo_equals_single_process(total, chunk):
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it starts its two ranks under
     torch.distributed.run as a child process and passes their exit code on: on a box without a
-    GPU every rank stops at "needs a GPU", never at "needs torch.distributed.run"."""
+    GPU the ranks stop at "needs a GPU", never at "needs torch.distributed.run"."""
     import subprocess
     import sys
     if torch.cuda.is_available():
@@ -118,5 +118,5 @@ def test_bench_launches_its_own_ranks():
                        text=True, timeout=300)
     text = r.stdout + r.stderr
     assert r.returncode != 0
-    assert text.count("bench.py needs a GPU") == 2, text[-2000:]
+    assert text.count("bench.py needs a GPU") >= 1, text[-2000:]   # (the launcher stops the other rank)
     assert "needs torch.distributed.run" not in text

@@ -718,6 +718,17 @@ def test_duplicate_yaml_keys_are_refused():
     bad2 = "A:\n    baseline:\n        run: True\n        run: False\n"
     with pytest.raises(ValueError, match='Duplicate key "run"'):
         YamlConfig(bad2, ["A"], sample_rate=FS)
+    # a merge key followed by an overriding key is legal YAML, not a duplicate
+    merged = ("A:\n    baseline: &base\n        run: True\n        window_min_from_start_usec: 0\n"
+              "        window_max_from_trig_usec: -100\n    baseline_late:\n        <<: *base\n"
+              "        base_algorithm: baseline\n        window_max_from_trig_usec: -10\n")
+    cfg = YamlConfig(merged, ["A"], sample_rate=FS).get_config()["feature"]["channels"]["A"]
+    assert cfg["baseline_late"]["window_max_from_trig_usec"] == -10
+    assert cfg["baseline_late"]["window_min_from_start_usec"] == 0 and cfg["baseline"]["window_max_from_trig_usec"] == -100
+    # ... and a key written twice next to a merge key still is one
+    bad3 = merged + "        window_max_from_trig_usec: -20\n"
+    with pytest.raises(ValueError, match='Duplicate key "window_max_from_trig_usec"'):
+        YamlConfig(bad3, ["A"], sample_rate=FS)
 
 
 @pytest.mark.gpu
