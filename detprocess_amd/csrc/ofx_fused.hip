@@ -40,6 +40,7 @@
 #include "ofx_common.h"
 #include "ofx_device.h"
 #include "ofx_fft_regs.h"
+#include "ofx_fused_host.h"
 
 using namespace ofxfft;
 
@@ -50,6 +51,9 @@ namespace {
 #endif
 constexpr int VT = OFX_VT;         // virtual threads per hardware thread
 constexpr int FN = 32768;          // samples
+#define GEO_N FN                   // (the names the shared fragments ofx_fused_*.inc use)
+#define GEO_WIDE WIDE
+#define GEO_LDS_BINS NLOW_MAX
 constexpr int FM = 16384;          // packed complex points
 constexpr int FV = 512;            // virtual threads
 constexpr int FT = FV / VT;        // hardware threads per workgroup
@@ -133,68 +137,7 @@ struct FusedLds {                  // one per trace in flight (per half)
 constexpr size_t FUSED_LDS_BYTES = sizeof(FusedShared) + NHALF * sizeof(FusedLds);
 static_assert(FUSED_LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
 
-// Phase markers: an assembly comment (";ofxphase i") to find the phases in the ISA
-// (hipcc -S; tools/isa_phases.py counts instructions per phase).
-#ifndef OFX_STAMPS
-#define STAMP(i) asm volatile(";ofxphase " #i)
-#else
-// Diagnostic build (-DOFX_STAMPS, tools/phase_timeline.py): every wave writes the shader clock at
-// every phase marker of its first OFX_STAMP_TRACES traces into the buffer passed in place of
-// `xwide` ([workgroup][trace][wave][16]; slot 13: HW_ID, slot 14: XCC_ID) with SCALAR stores --
-// no branch, no exec-mask change, so the scheduling regions of the product build stay as they
-// are -- so that the phases of the two workgroups of a CU can be laid over each other.  No
-// output depends on the stamps.
-#define OFX_STAMP_TRACES 40
-__device__ __forceinline__ void ofx_stamp(unsigned long long* p) {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0"
-                 : "=&s"(t) : "s"(p));
-}
-// slot 15: the constant 100 MHz counter at stamp 0 -- shader clock in the kernel =
-// d(s_memtime) / d(s_memrealtime) x 100 MHz between the stamps 0 of consecutive traces
-// (MI355X_MICROARCH.md, DVFS note (6); tools/phase_timeline.py reports it as clock_mhz)
-__device__ __forceinline__ void ofx_stamp_rt(unsigned long long* p) {
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x78"
-                 : "=&s"(t) : "s"(p));
-}
-__device__ __forceinline__ void ofx_stamp_id(unsigned long long* p) {
-    unsigned a, b;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\t"
-                 "s_store_dword %0, %2, 0x68\n\ts_store_dword %1, %2, 0x70"
-                 : "=&s"(a), "=&s"(b) : "s"(p));
-}
-// -DOFX_TAILSTAMPS (with -DOFX_STAMPS): the stamps 2..9 of the transform phases are dropped and their
-// slots carry the sub-phases of the tail instead (TSTAMP(2..9); tools/dev_tail_timeline.py).
-#ifdef OFX_TAILSTAMPS
-constexpr bool TAILMODE = true;
-#else
-constexpr bool TAILMODE = false;
-#endif
-#define STAMP_AT(i)                                                                           \
-    do {                                                                                      \
-        asm volatile(";ofxphase " #i);                                                        \
-        {   /* no branch: traces beyond the last slot keep overwriting it */                  \
-            const int si_ = stamp_it < OFX_STAMP_TRACES - 1 ? stamp_it : OFX_STAMP_TRACES - 1; \
-            unsigned long long* sb_ = stamp_base + (size_t)si_ * (NWAVE * 16);                \
-            ofx_stamp(sb_ + (i));                                                             \
-            if ((i) == 0) ofx_stamp_id(sb_);                                                  \
-            if ((i) == 0) ofx_stamp_rt(sb_);                                                  \
-            if ((i) == 12) ++stamp_it;                                                        \
-        }                                                                                     \
-    } while (0)
-#define STAMP(i)                                                                              \
-    do {                                                                                      \
-        if constexpr (!(TAILMODE && (i) >= 2 && (i) <= 9)) STAMP_AT(i);                       \
-    } while (0)
-#define TSTAMP(i)                                                                             \
-    do {                                                                                      \
-        if constexpr (TAILMODE) STAMP_AT(i);                                                  \
-    } while (0)
-#endif
-#ifndef TSTAMP
-#define TSTAMP(i)
-#endif
+#include "ofx_fused_stamps.h"
 
 struct FusedTabs {
     const float2* t1;     // [5][512] float4 rows of stage-1 twiddle anchors (see T1Anch)
@@ -216,25 +159,7 @@ struct FusedSlotArg {
 
 __device__ __forceinline__ int partner_block(int v) { return v == 0 ? 512 : 1024 - v; }
 
-// Buffer loads: descriptor in SGPRs, one 32-bit VGPR byte offset per lane, the
-// row offset in an SGPR -- no per-row 64-bit VGPR addresses to keep alive.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-#ifdef ABL_NOTAB
-    return make_float4(0.5f + voff * 1e-9f, 0.25f, 0.125f + soff * 1e-9f, 0.7f);
-#endif
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                       __uint_as_float(v.w));
-}
-__device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return mk(__uint_as_float(v.x), __uint_as_float(v.y));
-}
+#include "ofx_fused_parts.h"
 __device__ __forceinline__ float max3f(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
@@ -245,32 +170,7 @@ __device__ __forceinline__ float min3f(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
-__device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
 
-// ---- the pairwise middle step on one (Z_k, Z_p) slot -------------------------
-// in : zk = Z_k, zp = Z_p (p = M - k)      out: zk = Z'_k, zp = Z'_p
-// chi accumulates the chi2_0 contribution lane-wise (re^2 and im^2 terms); xk2 = 2 X_k,
-// xp2 = 2 conj(X_p).
-// T = i t_k, tw = (W_k / 2, conj(W_p) / 2), g = (g_k', g_p').  20 packed instructions.
-__device__ __forceinline__ void mid_slot(cpx& zk, cpx& zp, const cpx T, const float4 tw,
-                                         const cpx g, cpx& xk2, cpx& xp2, cpx& chi) {
-    const cpx wk = lo2(tw), wp = hi2(tw);
-    const cpx u = pfma(zp, mk(1.0f, -1.0f), zk);             // Z_k + conj(Z_p)
-    const cpx w = pfma(zp, mk(-1.0f, 1.0f), zk);             // Z_k - conj(Z_p)
-    const cpx sv = cmul(w, T);                               // i t w
-    xk2 = u - sv;                                            // 2 X_k
-    xp2 = u + sv;                                            // 2 conj(X_p)
-    chi = pfma(xk2 * xk2, g.xx, chi);
-    chi = pfma(xp2 * xp2, g.yy, chi);
-    const cpx yk = cmul(xk2, wk);
-    const cpx yp = cmul(xp2, wp);
-    const cpx sg = yk + yp;
-    const cpx df = yk - yp;
-    const cpx q = cmulc(df, T);                              // = -(i conj(t) df)
-    zk = sg - q;
-    zp = conj_sum(sg, q);
-}
 
 // Middle step over the 32 values of a virtual thread at d[O .. O+32).
 // A = d[O+0..15] (block k_low = v), B = d[O+16..31] (partner block).  Generic: slot j
@@ -770,21 +670,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             tdpar ^= 1;
             // end points of the slice owned by thread w (trapezoid correction): requested
             // first, consumed after the reductions
-            float first = 0.f, last = 0.f;
-            if (tid < pd.n_tdwin) {
-                const int lo = pd.tdw[tid].lo, hi = pd.tdw[tid].hi;
-                const float* e = traces + (size_t)b * ev_stride;
-                if constexpr (FEAT & 4) {
-                    for (int c = 0; c < pd.n_terms; ++c) {
-                        const float* z = e + (size_t)pd.chan[c] * FN;
-                        first = fmaf(pd.weight[c], z[lo], first);
-                        last = fmaf(pd.weight[c], z[hi - 1], last);
-                    }
-                } else {
-                    first = e[lo];
-                    last = e[hi - 1];
-                }
-            }
+#include "ofx_fused_td_endpoints.inc"
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
@@ -840,26 +726,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
                 }
             }
             __syncthreads();
-            if (tid < pd.n_tdwin && !skip) {             // one thread finalises one window
-                const int w = tid;
-                const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-                float S = 0.f, SQ = 0.f, MX = -INFINITY, MN = INFINITY;
-                for (int q = 0; q < NWAVE; ++q) {
-                    S += L.tdred[tdpar][w][0][q];
-                    MX = fmaxf(MX, L.tdred[tdpar][w][1][q]);
-                    MN = fminf(MN, L.tdred[tdpar][w][2][q]);
-                    SQ += L.tdred[tdpar][w][3][q];
-                }
-                float* o = row + pd.tdw[w].out_off;
-                o[OFX_TD_BASELINE] = S / (float)(hi - lo);
-                o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
-                o[OFX_TD_MAXIMUM] = MX;
-                o[OFX_TD_MINIMUM] = MN;
-                o[OFX_TD_SUM] = S;
-                o[OFX_TD_SUMSQ] = SQ;
-                o[OFX_TD_FIRST] = first;
-                o[OFX_TD_LAST] = last;
-            }
+#include "ofx_fused_td_finalize.inc"
         }
         if ((MULTI ? nslots : sd.n_search) == 0) {
             have = false;
@@ -1240,45 +1107,10 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         const __amdgpu_buffer_rsrc_t rxw =
             make_rsrc(xwide + (WIDE ? (size_t)wg * (NS_MAX - NLOW_MAX) : 0),
                       WIDE ? (nstash - NLOW_MAX) * 8 : 0);
-        if (pd.n_bands > 0 && slot_i == 0) {
-            const float cpsd = 0.25f / ((float)FN * pd.fs);      // (2 X)^2 / 4 / (N fs)
-            for (int i = wave_t; i < pd.n_bands; i += NWAVE) {
-                const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
-                float acc = 0.0f;
-                for (int k = lo + lane_t; k < hi; k += 64) {
-                    cpx x2;
-                    if (!WIDE || k < NLOW_MAX) x2 = L.xlow[k];
-                    else x2 = buf_ld2(rxw, (k - NLOW_MAX) * 8, 0);
-                    acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
-                }
-                acc = ofx_wave_sum(acc);
-                if (lane_t == 0 && !skip) row[pd.band[i].out_off] = acc / (float)(hi - lo);
-            }
-        }
+#include "ofx_fused_bands.inc"
 
         // The fit of search q (uniform): no-delay lag, full-range winner or window winner.
-        auto resolve = [&](const OfxSearchDev& sq, int q) {
-            OfxCand best;
-            const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
-                              sq.hi == FN;
-            if (sq.kind == OFX_SEARCH_NODELAY) {
-                best.amp = a_lag0;
-                best.idx = pre;
-                best.key = a_lag0 * a_lag0;
-            } else if (full) {
-                best = fullbest;
-            } else {
-                best = ofx_cand_none();
-                if constexpr (FEAT & 1) {
-#pragma unroll
-                    for (int w = 0; w < NWAVE; ++w) {
-                        const OfxCand o = L.wc[q][w];
-                        if (ofx_cand_better(o.key, o.idx, best)) best = o;
-                    }
-                }
-            }
-            return best;
-        };
+#include "ofx_fused_resolve.inc"
         // interpolate=True: amplitudes at the rolled bins idx -+ 1 (the last readers of d)
         if constexpr (FEAT & 1) {
 #pragma unroll 1
@@ -1439,15 +1271,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         // behind it the first barrier of the next trace held the other three waves
         // (profiles/r02_phase_timeline_before.json: 9.3 k cycles in "tailB").
         __syncthreads();
-        if (tt < SDX.n_search && !skip) {
-            const int q = tt;
-            float lw = 0.0f;
-            for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
-            const OfxRefined* rp = nullptr;
-            if constexpr (FEAT & 1)
-                if (SDX.search[q].interp) rp = &L.ref[q];
-            ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
-        }
+#include "ofx_fused_row_write.inc"
         TSTAMP(8);                               // barrier, row write
         // d and every table value are dead: request the next trace; its HBM latency hides
         // under the loop overhead and the first stages of the other workgroup
@@ -1646,11 +1470,7 @@ static int fused_tables(ofx_plan* p) {
         const double a = -PI2 * (double)v / FN;
         t2[32 * 16 + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
     }
-    OFX_HIP(hipMalloc(&p->d_tw1, sizeof(float2) * t1.size()));
-    OFX_HIP(hipMalloc(&p->d_tw2, sizeof(float2) * t2.size()));
-    OFX_HIP(hipMemcpy(p->d_tw1, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
-    OFX_HIP(hipMemcpy(p->d_tw2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
-    return OFX_OK;
+    return fused_upload_tables(p, t1, t2);
 }
 
 // Build the middle-step tables of one slot from the fp64 one-sided filter.
@@ -1723,13 +1543,7 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
     if (MULTI) {
         // per-workgroup spectrum scratch (sized for the full grid, allocated once)
         const size_t need = (size_t)p->cu_count * WG_PER_CU * NHALF * NV * FT * sizeof(float2);
-        if (p->fused_spec_bytes < need) {
-            if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
-            p->d_fused_spec = nullptr;
-            p->fused_spec_bytes = 0;
-            OFX_HIP(hipMalloc(&p->d_fused_spec, need));
-            p->fused_spec_bytes = need;
-        }
+        if (int rcs = fused_ensure_spec(p, need)) return rcs;
     }
     if ((FEAT & 8) && !p->d_fused_xwide)   // per-workgroup stash of the bins 512 .. NS_MAX-1
         OFX_HIP(hipMalloc(&p->d_fused_xwide, (size_t)p->cu_count * WG_PER_CU * NHALF *
@@ -1755,16 +1569,8 @@ static int launch(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
 #ifdef OFX_STAMPS
-    if (const char* f = getenv("OFX_STAMP_FILE")) {
-        OFX_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h(stamp_bytes / 8);
-        OFX_HIP(hipMemcpy(h.data(), reinterpret_cast<char*>(p->d_fused_xwide) + stash_bytes,
-                          stamp_bytes, hipMemcpyDeviceToHost));
-        if (FILE* fp = fopen(f, "wb")) {
-            fwrite(h.data(), 8, h.size(), fp);
-            fclose(fp);
-        }
-    }
+    if (int rcd = fused_dump_stamps(st, reinterpret_cast<char*>(p->d_fused_xwide) + stash_bytes, stamp_bytes))
+        return rcd;
 #endif
     return OFX_OK;
 }
@@ -1809,17 +1615,6 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     if (ofx_fused12_supported(p->N)) return ofx_fused12_process(p, d_traces, d_valid, n, d_out, st);
     if (ofx_fused20_supported(p->N)) return ofx_fused20_process(p, d_traces, d_valid, n, d_out, st);
     if (p->N != FN) return ofx_fused25_process(p, d_traces, d_valid, n, d_out, st);
-    OfxPlanDev pd;
-    ofx_fill_plan_dev(p, &pd);
-    for (int w = 0; w < pd.n_tdwin; ++w) {          // row classification of the window sums
-        pd.tdw[w].full = pd.tdw[w].edge = 0;
-        for (int n1 = 0; n1 < 32; ++n1) {
-            const int r0 = 1024 * n1, lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-            if (r0 + 1024 <= lo || r0 >= hi) continue;
-            if (lo <= r0 && r0 + 1024 <= hi) pd.tdw[w].full |= 1u << n1;
-            else pd.tdw[w].edge |= 1u << n1;
-        }
-    }
     int rc = fused_tables(p);
     if (rc) return rc;
     FusedTabs common;
@@ -1834,99 +1629,20 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     common.midW = reinterpret_cast<const float4*>(p->d_tw1);   // never read without searches
     common.midG = p->d_tw1;
 
-    std::vector<FusedSlotArg> args;
-    int feat = 0;
-    int nstash = 0;                 // bins of 2 X_k the tail reads back
-    for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
-        if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
-        FusedSlotArg a;
-        memset(&a, 0, sizeof(a));
-        ofx_fill_slot_dev(p, s, &a.sd);
-        a.tabs = common;
-        a.tabs.midW = p->slot[s].d_pq;
-        a.tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * FV);
-        a.tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
-        a.tabs.gq = p->slot[s].gq;
-        for (int q = 0; q < a.sd.n_search; ++q) {
-            const OfxSearchDev& sq = a.sd.search[q];
-            if (sq.kind == OFX_SEARCH_DELAY &&
-                (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
-                feat |= 1;
-            if (sq.kind == OFX_SEARCH_DELAY && !(sq.lo == 0 && sq.hi == p->N && !sq.outside)) {
-                // register rows of the lags n = (i - pre) mod N the search visits
-                auto mark = [&](int i0, int i1) {
-                    for (int i = i0; i < i1;) {
-                        const int nl = (i - p->pre) & (FN - 1);
-                        a.tabs.rowmask |= 1u << (nl >> 10);
-                        i += 1024 - (nl & 1023);                 // first lag of the next row
-                    }
-                    if (i1 > i0) a.tabs.rowmask |= 1u << (((i1 - 1 - p->pre) & (FN - 1)) >> 10);
-                };
-                if (sq.outside) {
-                    mark(0, sq.lo);
-                    mark(sq.hi, FN);
-                } else {
-                    mark(sq.lo, sq.hi);
-                }
-            }
-            if (sq.nlow > NS_MAX || (sq.nlow > NLOW_MAX && VT != 2)) {
-                ofx_set_error("FUSED engine: lowchi2_fcutoff covers %d bins (> %d)", sq.nlow,
-                              VT == 2 ? NS_MAX : NLOW_MAX);
-                return OFX_ERR_UNSUPPORTED;
-            }
-            if (sq.nlow > nstash) nstash = sq.nlow;
-        }
-        args.push_back(a);
-    }
-    const int nslots = (int)args.size();
-    if (pd.n_bands > 0) {
-        if (nslots == 0) {
-            ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
-                          "search on the plan (use the ROCFFT engine otherwise)");
-            return OFX_ERR_UNSUPPORTED;
-        }
-        for (int i = 0; i < pd.n_bands; ++i)
-            if (pd.band[i].k_hi > (VT == 2 ? NS_MAX : NLOW_MAX)) {
-                ofx_set_error("FUSED engine: band [%d,%d) exceeds the %d stashed bins",
-                              pd.band[i].k_lo, pd.band[i].k_hi, VT == 2 ? NS_MAX : NLOW_MAX);
-                return OFX_ERR_UNSUPPORTED;
-            } else if (pd.band[i].k_hi > nstash) {
-                nstash = pd.band[i].k_hi;
-            }
-    }
-    if (pd.n_tdwin > 0) feat |= 2;
-    if (nstash > NLOW_MAX) feat |= 8;
-    if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
-
-    if (nslots <= 1) {
-        OfxSlotDev sd;
-        memset(&sd, 0, sizeof(sd));
-        FusedTabs tabs = common;
-        if (nslots == 1) {
-            sd = args[0].sd;
-            tabs = args[0].tabs;
-        }
-        return launch_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, nullptr,
-                                  nslots, nstash);
-    }
-    // several slots: upload the slot table (from a buffer owned by the plan: the copy is
-    // asynchronous on the stream)
-    const size_t bytes = sizeof(FusedSlotArg) * (size_t)nslots;
-    if (!p->d_fused_slots)
-        OFX_HIP(hipMalloc(&p->d_fused_slots, sizeof(FusedSlotArg) * OFX_MAX_SLOTS));
-    if (p->fused_slot_stamp != p->filter_stamp) {
-        OFX_HIP(hipStreamSynchronize(st));      // an earlier launch may still read the table
-        p->h_slot_args.assign(reinterpret_cast<const unsigned char*>(args.data()),
-                              reinterpret_cast<const unsigned char*>(args.data()) + bytes);
-        OFX_HIP(hipMemcpyAsync(p->d_fused_slots, p->h_slot_args.data(), bytes,
-                               hipMemcpyHostToDevice, st));
-        p->fused_slot_stamp = p->filter_stamp;
-    }
-    OfxSlotDev sd0;
-    memset(&sd0, 0, sizeof(sd0));
-    return launch_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,
-                             reinterpret_cast<const FusedSlotArg*>(p->d_fused_slots), nslots,
-                             nstash);
+    struct G {
+        enum { N = FN, ROWS = 1024, NROWS = 32, LDS_BINS = NLOW_MAX,
+               MAX_BINS = (VT == 2) ? NS_MAX : NLOW_MAX, MIDG_OFF = 16 * FV };
+        using Tabs = FusedTabs;
+        using SlotArg = FusedSlotArg;
+    };
+    return fused_process_plan<G>(p, common, st, [&](bool multi, int feat, const OfxPlanDev& pd,
+                                                    const OfxSlotDev& sd, const FusedTabs& tabs,
+                                                    const FusedSlotArg* d_slots, int nslots, int nstash) {
+        return multi ? launch_feat<true>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
+                                         nslots, nstash)
+                     : launch_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
+                                          nslots, nstash);
+    });
 }
 
 // ---- the transform on its own (rows of 16384 complex points; used by the N x M engine)

@@ -36,6 +36,7 @@
 #include "ofx_common.h"
 #include "ofx_device.h"
 #include "ofx_fft_mixed.h"
+#include "ofx_fused_host.h"
 
 using namespace ofxfft;
 
@@ -65,6 +66,9 @@ constexpr int R1 = OFX25_R1, R2 = 25, R3 = 25;
 static_assert(R1 == 20 || R1 == 16 || R1 == 10, "supported first-stage lengths");
 constexpr int GM = R1 * R2 * R3;        // 12500 packed complex points
 constexpr int GN = 2 * GM;              // 25000 samples
+#define GEO_N GN                        // (the names the shared fragments ofx_fused_*.inc use)
+#define GEO_WIDE false
+#define GEO_LDS_BINS NLOW_MAX
 constexpr int GP = R1 * R2;             // 500 blocks of R3 bins
 constexpr int GT = GP / 2;              // 250 working threads
 constexpr int BLK = (GT + 63) / 64 * 64;    // 256
@@ -127,31 +131,7 @@ struct Lds25 {
 constexpr size_t LDS_BYTES = sizeof(Shared25) + sizeof(Lds25);
 static_assert(LDS_BYTES * WG_PER_CU <= 160 * 1024, "LDS budget");
 
-#ifndef OFX_STAMPS
-#define STAMP(i) asm volatile(";ofxphase " #i)
-#define SUBSTAMP(i)
-#else
-#define SUBSTAMP(i) STAMP(i)
-// Diagnostic build (-DOFX_STAMPS, tools/phase_timeline.py --n25000): as in ofx_fused.hip, every
-// wave writes the shader clock at every phase marker of its first OFX_STAMP_TRACES traces with
-// scalar stores ([workgroup][trace][wave][16]; the buffer is passed in place of `spec`).
-#define OFX_STAMP_TRACES 40
-__device__ __forceinline__ void ofx_stamp(unsigned long long* p) {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_store_dwordx2 %0, %1, 0x0"
-                 : "=&s"(t) : "s"(p));
-}
-#define STAMP(i)                                                                              \
-    do {                                                                                      \
-        asm volatile(";ofxphase " #i);                                                        \
-        {                                                                                     \
-            const int si_ = stamp_it < OFX_STAMP_TRACES - 1 ? stamp_it : OFX_STAMP_TRACES - 1; \
-            unsigned long long* sb_ = stamp_base + (size_t)si_ * (NWAVE * 16);                \
-            ofx_stamp(sb_ + (i));                                                             \
-            if ((i) == 12) ++stamp_it;                                                        \
-        }                                                                                     \
-    } while (0)
-#endif
+#include "ofx_fused_stamps.h"
 
 struct Tabs25 {
     const float2* t1;     // [2][640] float4 rows of stage-1 twiddle anchors
@@ -177,48 +157,10 @@ struct SlotArg25 {
     Tabs25 tabs;
 };
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
-                       __uint_as_float(v.w));
-}
-__device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-    return mk(__uint_as_float(v.x), __uint_as_float(v.y));
-}
+#include "ofx_fused_parts.h"
 // (plain fmaxf / fminf: the compiler forms v_max3_f32 / v_min3_f32 itself)
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }
-__device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
-__device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
-__device__ __forceinline__ cpx cconj(cpx z) { return z * mk(1.0f, -1.0f); }
-
-// The pairwise middle step on one (Z_k, Z_p) slot, p = M - k (same algebra as ofx_fused.hip):
-// in zk = Z_k, zp = Z_p; out zk = Z'_k, zp = Z'_p; xk2 = 2 X_k, xp2 = 2 conj(X_p).
-// T = i t_k, tw = (W_k / 2, conj(W_p) / 2), g = (g_k', g_p').
-__device__ __forceinline__ void mid_slot(cpx& zk, cpx& zp, const cpx T, const float4 tw,
-                                         const cpx g, cpx& xk2, cpx& xp2, cpx& chi) {
-    const cpx wk = lo2(tw), wp = hi2(tw);
-    const cpx u = pfma(zp, mk(1.0f, -1.0f), zk);             // Z_k + conj(Z_p)
-    const cpx w = pfma(zp, mk(-1.0f, 1.0f), zk);             // Z_k - conj(Z_p)
-    const cpx sv = cmul(w, T);
-    xk2 = u - sv;
-    xp2 = u + sv;
-    chi = pfma(xk2 * xk2, g.xx, chi);
-    chi = pfma(xp2 * xp2, g.yy, chi);
-    const cpx yk = cmul(xk2, wk);
-    const cpx yp = cmul(xp2, wp);
-    const cpx sg = yk + yp;
-    const cpx df = yk - yp;
-    const cpx q = cmulc(df, T);
-    zk = sg - q;
-    zp = conj_sum(sg, q);
-}
 
 // Thread 0 owns the self-paired blocks A0 = block 0 (bins 500 j) and B0 = block 250
 // (bins 250 + 500 j).  A permutation of its 50 values brings them to the generic slot shape
@@ -540,21 +482,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
         // Sample index of d[20 h + n1].{x,y} is 1250 n1 + 2 vt + {0,1}, vt = tid + 250 h.
         if constexpr (FEAT & 2) {
             tdpar ^= 1;
-            float first = 0.f, last = 0.f;
-            if (tid < pd.n_tdwin) {
-                const int lo = pd.tdw[tid].lo, hi = pd.tdw[tid].hi;
-                const float* e = traces + (size_t)b * ev_stride;
-                if constexpr (FEAT & 4) {
-                    for (int c = 0; c < pd.n_terms; ++c) {
-                        const float* z = e + (size_t)pd.chan[c] * GN;
-                        first = fmaf(pd.weight[c], z[lo], first);
-                        last = fmaf(pd.weight[c], z[hi - 1], last);
-                    }
-                } else {
-                    first = e[lo];
-                    last = e[hi - 1];
-                }
-            }
+#include "ofx_fused_td_endpoints.inc"
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
                 // sums of rounds 0, 1 (sa, sqa: masked by `act` at the end -- idle lanes are mirrors)
@@ -624,26 +552,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
                 }
             }
             __syncthreads();
-            if (tid < pd.n_tdwin) {
-                const int w = tid;
-                const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-                float S = 0.f, SQ = 0.f, MX = -INFINITY, MN = INFINITY;
-                for (int q = 0; q < NWAVE; ++q) {
-                    S += L.tdred[tdpar][w][0][q];
-                    MX = fmaxf(MX, L.tdred[tdpar][w][1][q]);
-                    MN = fminf(MN, L.tdred[tdpar][w][2][q]);
-                    SQ += L.tdred[tdpar][w][3][q];
-                }
-                float* o = row + pd.tdw[w].out_off;
-                o[OFX_TD_BASELINE] = S / (float)(hi - lo);
-                o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
-                o[OFX_TD_MAXIMUM] = MX;
-                o[OFX_TD_MINIMUM] = MN;
-                o[OFX_TD_SUM] = S;
-                o[OFX_TD_SUMSQ] = SQ;
-                o[OFX_TD_FIRST] = first;
-                o[OFX_TD_LAST] = last;
-            }
+#include "ofx_fused_td_finalize.inc"
         }
         if ((MULTI ? nslots : sd.n_search) == 0) {
             have = false;
@@ -1070,42 +979,10 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
         }
 
         // psd_amp bands from the stashed 2 X_k; one wave per band
-        if (pd.n_bands > 0 && slot_i == 0) {
-            const float cpsd = 0.25f / ((float)GN * pd.fs);
-            for (int i = wave_t; i < pd.n_bands; i += NWAVE) {
-                const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
-                float acc = 0.0f;
-                for (int k = lo + lane_t; k < hi; k += 64) {
-                    const cpx x2 = L.xlow[k];
-                    acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
-                }
-                acc = ofx_wave_sum(acc);
-                if (lane_t == 0) row[pd.band[i].out_off] = acc / (float)(hi - lo);
-            }
-        }
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t rxw = make_rsrc(nullptr, 0);   // (no global stash at these lengths)
+#include "ofx_fused_bands.inc"
 
-        auto resolve = [&](const OfxSearchDev& sq, int q) {
-            OfxCand best;
-            const bool full = (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 &&
-                              sq.hi == GN;
-            if (sq.kind == OFX_SEARCH_NODELAY) {
-                best.amp = a_lag0;
-                best.idx = pre;
-                best.key = a_lag0 * a_lag0;
-            } else if (full) {
-                best = fullbest;
-            } else {
-                best = ofx_cand_none();
-                if constexpr (FEAT & 1) {
-#pragma unroll
-                    for (int w = 0; w < NWAVE; ++w) {
-                        const OfxCand o = L.wc[q][w];
-                        if (ofx_cand_better(o.key, o.idx, best)) best = o;
-                    }
-                }
-            }
-            return best;
-        };
+#include "ofx_fused_resolve.inc"
         // interpolate=True: amplitudes at the rolled bins idx -+ 1
         if constexpr (FEAT & 1) {
 #pragma unroll 1
@@ -1177,15 +1054,7 @@ __global__ __launch_bounds__(BLK, WG_PER_CU * NWAVE / 4) void k_fused25(   // (t
             }
             STAMP(11);
             __syncthreads();
-            if (tt < SDX.n_search) {
-                const int q = tt;
-                float lw = 0.0f;
-                for (int w = 0; w < NWAVE; ++w) lw += L.lowp[q][w];
-                const OfxRefined* rp = nullptr;
-                if constexpr (FEAT & 1)
-                    if (SDX.search[q].interp) rp = &L.ref[q];
-                ofx_write_search(row, SDX.search[q], SDX, pd.inv_fs, pre, chi0, L.fin[q], lw, rp);
-            }
+#include "ofx_fused_row_write.inc"
         }
         }
 #undef SDX
@@ -1412,11 +1281,7 @@ static int fused25_tables(ofx_plan* p) {
         const double a = -PI2 * (double)v / GN;
         t2[R2 * R3 + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
     }
-    OFX_HIP(hipMalloc(&p->d_tw1, sizeof(float2) * t1.size()));
-    OFX_HIP(hipMalloc(&p->d_tw2, sizeof(float2) * t2.size()));
-    OFX_HIP(hipMemcpy(p->d_tw1, t1.data(), sizeof(float2) * t1.size(), hipMemcpyHostToDevice));
-    OFX_HIP(hipMemcpy(p->d_tw2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
-    return OFX_OK;
+    return fused_upload_tables(p, t1, t2);
 }
 
 // Middle-step tables of one slot from the fp64 one-sided filter.
@@ -1474,13 +1339,7 @@ static int launch25(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, con
     long long grid = (long long)p->cu_count * WG_PER_CU;
     if (MULTI) {
         const size_t need = (size_t)p->cu_count * WG_PER_CU * 2 * R3 * BLK * sizeof(float2);
-        if (p->fused_spec_bytes < need) {
-            if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
-            p->d_fused_spec = nullptr;
-            p->fused_spec_bytes = 0;
-            OFX_HIP(hipMalloc(&p->d_fused_spec, need));
-            p->fused_spec_bytes = need;
-        }
+        if (int rcs = fused_ensure_spec(p, need)) return rcs;
     }
     if (grid > n) grid = n;
 #ifdef OFX_STAMPS
@@ -1501,15 +1360,7 @@ static int launch25(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, con
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
 #ifdef OFX_STAMPS
-    if (const char* f = getenv("OFX_STAMP_FILE")) {
-        OFX_HIP(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h(stamp_bytes / 8);
-        OFX_HIP(hipMemcpy(h.data(), p->d_fused_spec, stamp_bytes, hipMemcpyDeviceToHost));
-        if (FILE* fp = fopen(f, "wb")) {
-            fwrite(h.data(), 8, h.size(), fp);
-            fclose(fp);
-        }
-    }
+    if (int rcd = fused_dump_stamps(st, p->d_fused_spec, stamp_bytes)) return rcd;
 #endif
     return OFX_OK;
 }
@@ -1540,17 +1391,6 @@ static int launch25_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxS
 
 int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
                         float* d_out, hipStream_t st) {
-    OfxPlanDev pd;
-    ofx_fill_plan_dev(p, &pd);
-    for (int w = 0; w < pd.n_tdwin; ++w) {          // row classification of the window sums
-        pd.tdw[w].full = pd.tdw[w].edge = 0;
-        for (int n1 = 0; n1 < R1; ++n1) {
-            const int r0 = ROWS * n1, lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
-            if (r0 + ROWS <= lo || r0 >= hi) continue;
-            if (lo <= r0 && r0 + ROWS <= hi) pd.tdw[w].full |= 1u << n1;
-            else pd.tdw[w].edge |= 1u << n1;
-        }
-    }
     int rc = fused25_tables(p);
     if (rc) return rc;
     Tabs25 common;
@@ -1566,96 +1406,20 @@ int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
     common.midW = reinterpret_cast<const float4*>(p->d_tw1);
     common.midG = p->d_tw1;
 
-    std::vector<SlotArg25> args;
-    int feat = 0;
-    for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
-        if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
-        SlotArg25 a;
-        memset(&a, 0, sizeof(a));
-        ofx_fill_slot_dev(p, s, &a.sd);
-        a.tabs = common;
-        a.tabs.midW = p->slot[s].d_pq;
-        a.tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + R3 * VPAD);
-        a.tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
-        a.tabs.gq = p->slot[s].gq;
-        for (int q = 0; q < a.sd.n_search; ++q) {
-            const OfxSearchDev& sq = a.sd.search[q];
-            if (sq.kind == OFX_SEARCH_DELAY &&
-                (sq.interp || !(sq.lo == 0 && sq.hi == p->N && !sq.outside)))
-                feat |= 1;
-            if (sq.kind == OFX_SEARCH_DELAY && !(sq.lo == 0 && sq.hi == p->N && !sq.outside)) {
-                // rows of lags n = (i - pre) mod N for the rolled indices i the search visits
-                auto mark = [&](int i0, int i1) {
-                    for (int i = i0; i < i1;) {
-                        int nl = i - p->pre;
-                        if (nl < 0) nl += GN;
-                        a.tabs.rowmask |= 1u << (nl / ROWS);
-                        const int row_end = (nl / ROWS + 1) * ROWS;           // first lag of the next row
-                        i += std::max(1, row_end - nl);
-                    }
-                    if (i1 > i0) {
-                        int nl = i1 - 1 - p->pre;
-                        if (nl < 0) nl += GN;
-                        a.tabs.rowmask |= 1u << (nl / ROWS);
-                    }
-                };
-                if (sq.outside) {
-                    mark(0, sq.lo);
-                    mark(sq.hi, GN);
-                } else {
-                    mark(sq.lo, sq.hi);
-                }
-            }
-            if (sq.nlow > NLOW_MAX) {
-                ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", GN,
-                              sq.nlow, NLOW_MAX);
-                return OFX_ERR_UNSUPPORTED;
-            }
-        }
-        args.push_back(a);
-    }
-    const int nslots = (int)args.size();
-    if (pd.n_bands > 0) {
-        if (nslots == 0) {
-            ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
-                          "search on the plan (use the ROCFFT engine otherwise)");
-            return OFX_ERR_UNSUPPORTED;
-        }
-        for (int i = 0; i < pd.n_bands; ++i)
-            if (pd.band[i].k_hi > NLOW_MAX) {
-                ofx_set_error("FUSED engine (%d samples): band [%d,%d) exceeds the %d stashed bins", GN,
-                              pd.band[i].k_lo, pd.band[i].k_hi, NLOW_MAX);
-                return OFX_ERR_UNSUPPORTED;
-            }
-    }
-    if (pd.n_tdwin > 0) feat |= 2;
-    if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
-
-    if (nslots <= 1) {
-        OfxSlotDev sd;
-        memset(&sd, 0, sizeof(sd));
-        Tabs25 tabs = common;
-        if (nslots == 1) {
-            sd = args[0].sd;
-            tabs = args[0].tabs;
-        }
-        return launch25_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, nullptr,
-                                    nslots);
-    }
-    const size_t bytes = sizeof(SlotArg25) * (size_t)nslots;
-    if (!p->d_fused_slots) OFX_HIP(hipMalloc(&p->d_fused_slots, sizeof(SlotArg25) * OFX_MAX_SLOTS));
-    if (p->fused_slot_stamp != p->filter_stamp) {
-        OFX_HIP(hipStreamSynchronize(st));
-        p->h_slot_args.assign(reinterpret_cast<const unsigned char*>(args.data()),
-                              reinterpret_cast<const unsigned char*>(args.data()) + bytes);
-        OFX_HIP(hipMemcpyAsync(p->d_fused_slots, p->h_slot_args.data(), bytes, hipMemcpyHostToDevice,
-                               st));
-        p->fused_slot_stamp = p->filter_stamp;
-    }
-    OfxSlotDev sd0;
-    memset(&sd0, 0, sizeof(sd0));
-    return launch25_feat<true>(feat, p, pd, sd0, common, d_traces, d_valid, n, d_out, st,
-                               reinterpret_cast<const SlotArg25*>(p->d_fused_slots), nslots);
+    struct G {
+        enum { N = GN, ROWS = 2 * NV1, NROWS = R1, LDS_BINS = NLOW_MAX, MAX_BINS = NLOW_MAX,
+               MIDG_OFF = R3 * VPAD };
+        using Tabs = Tabs25;
+        using SlotArg = SlotArg25;
+    };
+    return fused_process_plan<G>(p, common, st, [&](bool multi, int feat, const OfxPlanDev& pd,
+                                                    const OfxSlotDev& sd, const Tabs25& tabs,
+                                                    const SlotArg25* d_slots, int nslots, int) {
+        return multi ? launch25_feat<true>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
+                                           nslots)
+                     : launch25_feat<false>(feat, p, pd, sd, tabs, d_traces, d_valid, n, d_out, st, d_slots,
+                                            nslots);
+    });
 }
 
 // ---- the transform on its own (ofx_ldsfft_* dispatch to these for GM-point rows)
