@@ -185,19 +185,19 @@ if __name__ == '__main__':
     if '--config2' in sys.argv:
         sys.argv.remove('--config2')
         a2 = run(int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 2, '/tmp/stamps2c.bin', config3=2)
-        rep = {'cycles_per_phase_config2': summarise(a2), 'overlap_2wg': overlap(a2)}
+        rep = {'workload': 'config2', 'cycles_per_phase_config2': summarise(a2), 'overlap_2wg': overlap(a2),
+               'clock_mhz': clock_mhz(a2)}
         json.dump(rep, open(sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline_c2.json', 'w'), indent=1)
         for k, v in rep['cycles_per_phase_config2'].items():
             print(f'{k:8s} {v:9.0f}')
         print(rep['overlap_2wg'])
-    print('clock in the kernel (MHz):', rep.get('clock_mhz'))
         sys.exit(0)
     if '--config3' in sys.argv:
         # BASELINE configs[3] (three slots, nine searches, windows, bands): the stamps of a trace
         # cover its last slot pass only (markers 5..12 are re-stamped per slot), the total is exact
         sys.argv.remove('--config3')
         a3 = run(int(sys.argv[1]) if len(sys.argv) > 1 else 65536, 2, '/tmp/stamps3.bin', config3=True)
-        rep = {'cycles_per_phase_config3_last_slot': summarise(a3)}
+        rep = {'workload': 'config3', 'cycles_per_phase_config3_last_slot': summarise(a3), 'clock_mhz': clock_mhz(a3)}
         json.dump(rep, open(sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/phase_timeline_c3.json', 'w'), indent=1)
         for k, v in rep['cycles_per_phase_config3_last_slot'].items():
             print(f'{k:8s} {v:9.0f}')
