@@ -451,9 +451,10 @@ static int engine_process(ofx_plan* p, const float* d_in, const uint8_t* d_valid
         return ofx_rocfft_process(p, d_in, d_valid, n, d_out, st);
     if (rc == OFX_ERR_UNSUPPORTED && p->engine_auto) {
         // (a FUSED plan of a length the LDS engine carries faster than the rocFFT pipeline, e.g.
-        // 25000 samples, tries that one first)
+        // 25000 or 4096 samples, tries that one first)
         const bool pow2 = (p->N & (p->N - 1)) == 0;
-        if (p->engine == OFX_ENGINE_FUSED && !pow2 && ofx_lds_supported(p->N)) {
+        const bool lds_wins = ofx_lds_supported(p->N) && !(pow2 && (p->N <= 2048 || p->N >= 16384));
+        if (p->engine == OFX_ENGINE_FUSED && lds_wins) {
             rc = ofx_lds_process(p, d_in, d_valid, n, d_out, st);
             if (rc != OFX_ERR_UNSUPPORTED) return rc;
         }

@@ -129,7 +129,7 @@ static int fused_process_plan(ofx_plan* p, const typename G::Tabs& common, hipSt
 
 // Per-workgroup scratch of the several-slots kernels (the parked spectrum), sized for the full grid and
 // allocated once per plan.
-static int fused_ensure_spec(ofx_plan* p, size_t need) {
+[[maybe_unused]] static int fused_ensure_spec(ofx_plan* p, size_t need) {
     if (p->fused_spec_bytes < need) {
         if (p->d_fused_spec) (void)hipFree(p->d_fused_spec);
         p->d_fused_spec = nullptr;

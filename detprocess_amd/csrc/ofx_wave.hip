@@ -1,0 +1,599 @@
+// ofx_wave.hip -- FUSED engine at 4096 samples (BASELINE configs[0]'s trace length): ONE WAVE PER TRACE.
+//
+// Path: FeatureExtractors.of1x1_nodelay / _unconstrained / _constrained + baseline / integral /
+// maximum / minimum / psd_amp on 4096-sample traces (detprocess/core/algorithms.py:277-570, 650-885,
+// 952-1044; processing_data.py:712-772), as ofx_fused.hip does at 32768 samples.
+//
+// A trace is packed as M = 2048 complex points z[m] = x[2m] + i x[2m+1] and lives in the registers of
+// ONE wave: 64 lanes x 32 complex values.  The transform is k_fused's at a smaller geometry,
+// M = 16 x 8 x 16 with m = 128 n1 + 16 n2 + n3, k = k1 + 16 k2 + 128 k3:
+//
+//   load  lane l reads z[128 n1 + l + 64 h], h = 0, 1 (512 contiguous bytes per load of the wave)
+//   F1    two 16-point DFTs over n1 per lane, x w_2048^{n' k1}, n' = l + 64 h
+//   E1    wave-local LDS transpose  D1[k1][n']
+//   F2    four 8-point DFTs over n2 per lane (k1 = (l >> 4) + 4 g, n3 = l & 15), x w_128^{n3 k2}
+//   E2    wave-local LDS transpose  D2[k1 + 16 k2][n3]  (row stride 17)
+//   F3    lane v owns the 16-point blocks k_low = v and 128 - v (v = 0: the self-paired 0 and 64)
+//   mid   slot j pairs bin v + 128 j with M - (v + 128 j): unpack, filter, chi2_0, re-pack in one
+//         lane -- the Hermitian-partner layout and lane 0's permutation are those of ofx_fused.hip
+//   I3 / E3 / I2 / E4 / I1  mirror images; then the amplitudes A(n) of all 4096 lags go to LDS in
+//         natural order and every search (no-delay, full range, window, outside a window,
+//         interpolated) scans its rolled range there: 64 lags per lane for a full-range fit
+//
+// What the one-wave geometry buys: NO WORKGROUP BARRIER anywhere -- the four exchanges and the
+// arg-max are wave-synchronous (LDS operations of a wave execute in order; __builtin_amdgcn_
+// wave_barrier only pins the compiler) -- and 8 independent traces in flight per CU (two 4-wave
+// workgroups, 20 KB of LDS per wave) instead of two.  A workgroup's waves share nothing but the
+// 1 KB stage-2 twiddle table.  Several filter slots on one plan are not carried (an AUTO plan runs
+// them on the LDS engine); everything else of the plan is.
+//
+// Roofline: HBM, 4096 x 4 + 16 B algorithmic per trace (SURVEY.md section 8d at this length).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ofx_common.h"
+#include "ofx_device.h"
+#include "ofx_fft_regs.h"
+#include "ofx_fused_host.h"
+
+using namespace ofxfft;
+
+namespace {
+
+constexpr int WN = 4096;            // samples
+constexpr int WM = 2048;            // packed complex points
+constexpr int WAVES = 4;            // waves (= traces in flight) per workgroup
+constexpr int WBLK = 64 * WAVES;
+constexpr int WNV = 32;             // complex values per lane
+constexpr int WLD2 = 17;            // D2 row stride (elements)
+constexpr int WXB = 128 * WLD2;     // exchange buffer, complex elements (>= 2048)
+constexpr int WLOW = 256;           // low bins 2 X_k kept in LDS (78 kHz at 1.25 MHz)
+constexpr int WROWS = 256;          // samples per register row n1
+constexpr int WG_PER_CU_W = 2;
+#define GEO_N WN
+
+struct WaveLds {                    // one per wave
+    cpx xb[WXB];                    // exchange buffer / lag dump (4096 floats)
+    cpx xlow[WLOW + 8];             // 2 X_k, k < 256
+    cpx perm[WNV];                  // lane 0's permutation bounce buffer
+};
+struct WaveShared {
+    cpx t2[8 * 16];                 // w_128^{n3 k2}, index k2 * 16 + n3
+    WaveLds w[WAVES];
+};
+static_assert(sizeof(WaveShared) * WG_PER_CU_W <= 160 * 1024, "LDS budget");
+
+struct WaveTabs {
+    const float2* t1;     // [16][128]  w_2048^{n' k1}
+    const float2* t2;     // [8][16]    w_128^{n3 k2}
+    const float4* midW;   // [16][64]   (W_k / 2, conj(W_p) / 2)   slot j, lane v
+    const float2* midG;   // [16][64]   (g_k', g_p')
+    const float2* tbase;  // [64]       T_v = i exp(-2 pi i v / N); T of slot j is T_v w_32^j
+    float2 tb0hi;         // base of lane 0 for its slots j >= 8 (block 64)
+    float2 wq;            // W_{M/2}
+    float gq;             // g_{M/2}
+};
+
+#include "ofx_fused_parts.h"
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
+__device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }
+
+// lane 0's two self-paired blocks (0 and 64) in the generic slot shape: the permutation of
+// ofx_fused.hip (blocks 0 and 512 there), genA = [A0[0..7], B0[0..7]], genB = [B0[8..15], A0[9..15], A0[0]]
+__device__ constexpr int wperm_in_src(int j) {
+    if (j < 8) return j;
+    if (j < 24) return j + 8;
+    return (j - 16 + 1) % 16;
+}
+__device__ constexpr int wperm_out_src(int j) {
+    if (j < 8) return j;
+    if (j < 16) return 16 + j - 1;
+    return j - 8;
+}
+
+template <int J>
+__device__ __forceinline__ void wmid(cpx (&d)[WNV], __amdgpu_buffer_rsrc_t rw, __amdgpu_buffer_rsrc_t rg,
+                                     int v, WaveLds& L, cpx tlo, cpx thi, cpx& chi) {
+    if constexpr (J < 16) {
+        // (the tables of the 64 lanes x 16 slots are 24 KB per filter: L1 / L2 resident, and eight
+        // waves per CU hide their latency -- no software pipeline here)
+        const float4 tw = buf_ld4(rw, v * 16, J * 64 * 16);
+        const cpx tg = buf_ld2(rg, v * 8, J * 64 * 8);
+        const cpx T = twmul<J, -1>(J < 8 ? tlo : thi);
+        cpx xk2, xp2;
+        mid_slot(d[J], d[16 + 15 - J], T, tw, tg, xk2, xp2, chi);
+        // low bins for lowchi2 / psd_amp: xk2 = 2 X_k, k = v + 128 J; xp2 = 2 conj(X_p),
+        // p = 128 (16 - J) - v (v != 0); lane 0's slots 8, 9 hold the bins 64 and 192.  No branch:
+        // what does not apply goes to the padding behind the stash.
+        if constexpr (J <= 1) L.xlow[v + 128 * J] = xk2;
+        if constexpr (J >= 14) L.xlow[v != 0 ? 128 * (16 - J) - v : WLOW + 1] = cconj(xp2);
+        if constexpr (J == 8 || J == 9) L.xlow[v == 0 ? 64 + 128 * (J - 8) : WLOW + 2] = xk2;
+        wmid<J + 1>(d, rw, rg, v, L, tlo, thi, chi);
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+// FEAT bit 1: time-domain windows; bit 2: channel algebra on load.
+template <int FEAT>
+__global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSlotDev sd, WaveTabs tabs,
+                                                            const float* __restrict__ traces,
+                                                            const uint8_t* __restrict__ valid,
+                                                            long long n_traces, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    WaveShared& SH = *reinterpret_cast<WaveShared*>(smem_raw);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WaveLds& L = SH.w[wave];
+    for (int i = tid; i < 128; i += WBLK) SH.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
+    __syncthreads();                    // the only workgroup barrier of the kernel
+    const int pre = pd.pre;
+    const __amdgpu_buffer_rsrc_t rt1 = make_rsrc(tabs.t1, 16 * 128 * 8);
+    const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 64 * 8);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(tabs.midW, 16 * 64 * 16);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(tabs.midG, 16 * 64 * 8);
+    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, WLOW * 8);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, WLOW * 4);
+    const size_t ev_stride = (size_t)pd.n_channels * WN;
+    cpx* const xc = L.xb;
+    float* const xf = reinterpret_cast<float*>(L.xb);
+    // roles of this lane (loop-invariant, few)
+    const int k1q = lane >> 4, n3 = lane & 15;          // F2: k1 = k1q + 4 g
+    const int e1r = k1q * 128 + n3;                     // D1 read base: + 4 g * 128 + 16 n2
+    const int e2w = k1q * WLD2 + n3;                    // D2 write base: + (4 g + 16 k2) * WLD2
+    const int bB = (lane == 0) ? 64 : 128 - lane;       // partner block of this lane
+    cpx d[WNV];
+
+    const long long wstride = (long long)gridDim.x * WAVES;
+    for (long long b = (long long)blockIdx.x * WAVES + wave; b < n_traces; b += wstride) {
+        float* row = out + (size_t)b * pd.row;
+        if (valid && !valid[b]) {                       // wave-uniform
+            for (int j = lane; j < pd.row; j += 64) row[j] = OFX_SENTINEL;
+            continue;
+        }
+        // ------------------------------------------------ load (+ channel algebra)
+        {
+            const float* e = traces + (size_t)b * ev_stride;
+            const __amdgpu_buffer_rsrc_t rz =
+                make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * WN : 0), WN * 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) d[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
+            if constexpr (FEAT & 4) {
+                if (!(pd.n_terms == 1 && pd.weight[0] == 1.0f)) {
+                    const float w0 = pd.weight[0];
+#pragma unroll
+                    for (int j = 0; j < WNV; ++j) d[j] = d[j] * mk(w0, w0);
+                    for (int c = 1; c < pd.n_terms; ++c) {
+                        const __amdgpu_buffer_rsrc_t rc = make_rsrc(e + (size_t)pd.chan[c] * WN, WN * 4);
+                        const float wgt = pd.weight[c];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int n1 = 0; n1 < 16; ++n1) {
+                                const cpx s = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024);
+                                d[16 * h + n1] = pfma(mk(wgt, wgt), s, d[16 * h + n1]);
+                            }
+                    }
+                }
+            }
+        }
+        // ------------------------------------------------ time-domain windows
+        // sample index of d[16 h + n1].{x,y} is 256 n1 + 2 (lane + 64 h) + {0,1}
+        if constexpr (FEAT & 2) {
+            for (int w = 0; w < pd.n_tdwin; ++w) {
+                const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+                float s = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
+                cpx s2 = mk(0.0f, 0.0f), sq2 = mk(0.0f, 0.0f);
+                const unsigned fullm = pd.tdw[w].full, anym = fullm | pd.tdw[w].edge;
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    if (!((anym >> n1) & 1u)) continue;                   // uniform: outside
+                    if ((fullm >> n1) & 1u) {                             // uniform: full row
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const cpx v = d[16 * h + n1];
+                            s2 = s2 + v;
+                            sq2 = pfma(v, v, sq2);
+                            mx = max3f(mx, v.x, v.y);
+                            mn = min3f(mn, v.x, v.y);
+                        }
+                    } else {                                              // edge row
+                        const int lo_r = lo - WROWS * n1, hi_r = hi - WROWS * n1;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int c = 2 * (lane + 64 * h);
+                            const bool in0 = (c >= lo_r) && (c < hi_r);
+                            const bool in1 = (c >= lo_r - 1) && (c < hi_r - 1);
+                            const cpx v = d[16 * h + n1];
+                            const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
+                            s = (s + y0) + y1;
+                            sq = fmaf(y0, y0, fmaf(y1, y1, sq));
+                            mx = max3f(mx, in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY);
+                            mn = min3f(mn, in0 ? v.x : INFINITY, in1 ? v.y : INFINITY);
+                        }
+                    }
+                }
+                const float S = ofx_wave_sum(s + (s2.x + s2.y));
+                const float SQ = ofx_wave_sum(sq + (sq2.x + sq2.y));
+                const float MX = ofx_wave_max(mx);
+                const float MN = ofx_wave_min(mn);
+                if (lane == 0) {
+                    const float* e = traces + (size_t)b * ev_stride;
+                    float first = 0.f, last = 0.f;
+                    if constexpr (FEAT & 4) {
+                        for (int c = 0; c < pd.n_terms; ++c) {
+                            const float* z = e + (size_t)pd.chan[c] * WN;
+                            first = fmaf(pd.weight[c], z[lo], first);
+                            last = fmaf(pd.weight[c], z[hi - 1], last);
+                        }
+                    } else {
+                        first = e[lo];
+                        last = e[hi - 1];
+                    }
+                    float* o = row + pd.tdw[w].out_off;
+                    o[OFX_TD_BASELINE] = S / (float)(hi - lo);
+                    o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
+                    o[OFX_TD_MAXIMUM] = MX;
+                    o[OFX_TD_MINIMUM] = MN;
+                    o[OFX_TD_SUM] = S;
+                    o[OFX_TD_SUMSQ] = SQ;
+                    o[OFX_TD_FIRST] = first;
+                    o[OFX_TD_LAST] = last;
+                }
+            }
+        }
+        if (sd.n_search == 0) continue;
+        // ---------------------------------------------------------------- F1
+        dft<16, -1, WNV, 0>(d);
+        dft<16, -1, WNV, 16>(d);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1)
+                d[16 * h + k1] = cmul(d[16 * h + k1], buf_ld2(rt1, (lane + 64 * h) * 8, k1 * 1024));
+        // ---------------------------------------------------------------- E1: D1[k1][n']
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) xc[k1 * 128 + lane + 64 * h] = d[16 * h + k1];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) d[8 * g + n2] = xc[e1r + 512 * g + 16 * n2];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- F2
+        dft<8, -1, WNV, 0>(d);
+        dft<8, -1, WNV, 8>(d);
+        dft<8, -1, WNV, 16>(d);
+        dft<8, -1, WNV, 24>(d);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 1; k2 < 8; ++k2) d[8 * g + k2] = cmul(d[8 * g + k2], SH.t2[k2 * 16 + n3]);
+        // ---------------------------------------------------------------- E2: D2[k1 + 16 k2][n3]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) xc[e2w + (4 * g + 16 * k2) * WLD2] = d[8 * g + k2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d[j] = xc[lane * WLD2 + j];
+            d[16 + j] = xc[bB * WLD2 + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ------------------------------------------- F3, middle, I3 (registers)
+        dft<16, -1, WNV, 0>(d);
+        dft<16, -1, WNV, 16>(d);
+        cpx chi2v = mk(0.0f, 0.0f);
+        {
+            const cpx a8 = d[8];
+            if (lane == 0) {                            // lane 0: blocks 0 and 64 to the slot shape
+#pragma unroll
+                for (int j = 0; j < 32; ++j) L.perm[j] = d[j];
+                asm volatile("" ::: "memory");          // real LDS reads: no 24-value renaming under EXEC = lane 0
+#pragma unroll
+                for (int j = 8; j < 32; ++j) d[j] = L.perm[wperm_in_src(j)];
+            }
+            const cpx tb = buf_ld2(rtb, lane * 8, 0);
+            const cpx tbh = (lane == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;   // (kernel argument: a select)
+            wmid<0>(d, rw, rg, lane, L, tb, tbh, chi2v);
+            if (lane == 0) {
+                // self-paired bin k = M/2 (A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
+                const cpx zq = cmulc(a8, mk(tabs.wq.x, tabs.wq.y));
+                chi2v = pfma(a8 * a8, mk(2.0f * tabs.gq, 2.0f * tabs.gq), chi2v);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) L.perm[j] = d[j];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 9; j < 32; ++j) d[j] = L.perm[wperm_out_src(j)];
+                d[8] = zq + zq;
+            }
+        }
+        dft<16, +1, WNV, 0>(d);
+        dft<16, +1, WNV, 16>(d);
+        const float chi0 = ofx_wave_sum(chi2v.x + chi2v.y);
+        // ---------------------------------------------------------------- E3
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            xc[lane * WLD2 + j] = d[j];
+            xc[bB * WLD2 + j] = d[16 + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) d[8 * g + k2] = xc[e2w + (4 * g + 16 * k2) * WLD2];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- I2
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 1; k2 < 8; ++k2) d[8 * g + k2] = cmulc(d[8 * g + k2], SH.t2[k2 * 16 + n3]);
+        dft<8, +1, WNV, 0>(d);
+        dft<8, +1, WNV, 8>(d);
+        dft<8, +1, WNV, 16>(d);
+        dft<8, +1, WNV, 24>(d);
+        // ---------------------------------------------------------------- E4
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) xc[e1r + 512 * g + 16 * n2] = d[8 * g + n2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) d[16 * h + k1] = xc[k1 * 128 + lane + 64 * h];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- I1
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1)
+                d[16 * h + k1] = cmulc(d[16 * h + k1], buf_ld2(rt1, (lane + 64 * h) * 8, k1 * 1024));
+        dft<16, +1, WNV, 0>(d);
+        dft<16, +1, WNV, 16>(d);
+        // d[16 h + n1] = (A(2 m), A(2 m + 1)), m = 128 n1 + lane + 64 h: the lag dump in natural order
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = d[16 * h + n1];
+        __builtin_amdgcn_wave_barrier();
+        // ------------------------------------------------------------- tail: every search scans LDS
+        constexpr int NLK = WLOW / 64;
+        cpx lk_s[NLK];
+        float lk_g[NLK];
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            lk_s[i] = buf_ld2(rs_s, (lane + 64 * i) * 8, 0);
+            lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, (lane + 64 * i) * 4, 0, 0));
+        }
+        // psd_amp bands from the stashed 2 X_k (one band after the other: the wave is the workgroup here)
+        if (pd.n_bands > 0) {
+            const float cpsd = 0.25f / ((float)WN * pd.fs);
+            for (int i = 0; i < pd.n_bands; ++i) {
+                const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
+                float acc = 0.0f;
+                for (int k = lo + lane; k < hi; k += 64) {
+                    const cpx x2 = L.xlow[k];
+                    acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
+                }
+                acc = ofx_wave_sum(acc);
+                if (lane == 0) row[pd.band[i].out_off] = acc / (float)(hi - lo);
+            }
+        }
+#pragma unroll 1
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev& sq = sd.search[q];
+            OfxCand best = ofx_cand_none();
+            if (sq.kind == OFX_SEARCH_NODELAY) {
+                best.amp = xf[0];
+                best.idx = pre;
+                best.key = best.amp * best.amp;
+            } else {
+                auto scan = [&](int i0, int i1) {
+                    for (int i = i0 + lane; i < i1; i += 64) ofx_cand_take(best, xf[(i - pre) & (WN - 1)], i);
+                };
+                if (sq.outside) {
+                    scan(0, sq.lo);
+                    scan(sq.hi, WN);
+                } else {
+                    scan(sq.lo, sq.hi);
+                }
+                best = ofx_cand_wave_reduce(best);
+            }
+            OfxRefined ref;
+            ref.amp = best.amp;
+            ref.frac = 0.0f;
+            ref.chi2 = 0.0f;
+            const bool refine = sq.interp && best.idx != 0x7fffffff;
+            if (refine)
+                ref = ofx_interpolate(xf[(best.idx - 1 - pre) & (WN - 1)], best.amp,
+                                      xf[(best.idx + 1 - pre) & (WN - 1)], best.idx, WN, sd.norm, chi0);
+            // low-frequency chi2: the lane's bins are 64 apart, the phase runs along a chain
+            const int dl = best.idx - pre;
+            auto phase_of = [&](int k) {
+                const int m = (int)(((unsigned)k * (unsigned)dl) & (unsigned)(WN - 1));
+                float sn, cs;
+                sincospif(-2.0f * ((float)m + (float)k * ref.frac) / (float)WN, &sn, &cs);
+                return mk(cs, sn);
+            };
+            cpx ph = phase_of(lane);
+            const cpx step = phase_of(64);
+            float low = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) {
+                const int k = lane + 64 * i;
+                if (k < sq.nlow) {
+                    const cpx x2 = L.xlow[k];
+                    const float pr = ph.x * lk_s[i].x - ph.y * lk_s[i].y;
+                    const float pi = ph.x * lk_s[i].y + ph.y * lk_s[i].x;
+                    const float rr = 0.5f * x2.x - ref.amp * pr;
+                    const float ri = 0.5f * x2.y - ref.amp * pi;
+                    low += ((k == 0) ? 1.0f : 2.0f) * lk_g[i] * (rr * rr + ri * ri);
+                }
+                ph = cmul(ph, step);
+            }
+            low = ofx_wave_sum(low);
+            if (lane == 0) ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, low, refine ? &ref : nullptr);
+        }
+        __builtin_amdgcn_wave_barrier();            // the dump is read: the next trace may use the buffer
+    }
+}
+
+}  // namespace
+
+bool ofx_wave_supported(int n_samples) { return n_samples == WN; }
+
+static int wave_tables(ofx_plan* p) {
+    if (p->d_tw1) return OFX_OK;
+    const double PI2 = 6.283185307179586476925286766559;
+    std::vector<float2> t1(16 * 128), t2(8 * 16 + 64);
+    for (int k1 = 0; k1 < 16; ++k1)
+        for (int n = 0; n < 128; ++n) {
+            const double a = -PI2 * (double)((k1 * n) % WM) / WM;
+            t1[k1 * 128 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k2 = 0; k2 < 8; ++k2)
+        for (int n3 = 0; n3 < 16; ++n3) {
+            const double a = -PI2 * (double)((k2 * n3) % 128) / 128.0;
+            t2[k2 * 16 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int v = 0; v < 64; ++v) {          // tbase[v] = i exp(-2 pi i v / N), stored after t2
+        const double a = -PI2 * (double)v / WN;
+        t2[8 * 16 + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
+    }
+    return fused_upload_tables(p, t1, t2);
+}
+
+// Middle-step tables of one slot from the fp64 one-sided filter (the recipe of ofx_fused_prepare_slot
+// at this geometry): lane v, slot j -> bin k = v + 128 j (lane 0: 128 j for j < 8, 64 + 128 (j - 8)
+// above) and its partner M - k.
+int ofx_wave_prepare_slot(ofx_plan* p, int slot, const double* wf) {
+    int rc = wave_tables(p);
+    if (rc) return rc;
+    OfxSlotHost& h = p->slot[slot];
+    const std::vector<double>& g = h.g_host;
+    constexpr int NW = 16 * 64, NG = 8 * 64;
+    std::vector<float4> tab(NW + NG + 1);
+    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
+    auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
+    for (int v = 0; v < 64; ++v)
+        for (int j = 0; j < 16; ++j) {
+            int k;
+            if (v != 0) k = v + 128 * j;
+            else k = (j < 8) ? 128 * j : 64 + 128 * (j - 8);
+            const int pidx = (WM - k) % WM;
+            double wkr, wki, wpr, wpi, gk, gp;
+            if (k == 0) {                   // slot (DC, Nyquist): "p" is the Nyquist bin N/2 = M
+                W(0, wkr, wki);
+                W(WM, wpr, wpi);
+                gk = g[0] / 4.0;
+                gp = g[WM] / 4.0;
+            } else {
+                W(k, wkr, wki);
+                W(pidx, wpr, wpi);
+                gk = g[k] / 2.0;
+                gp = g[pidx] / 2.0;
+            }
+            tab[j * 64 + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0), (float)(wpr / 2.0),
+                                          (float)(-wpi / 2.0));
+            tg[j * 64 + v] = make_float2((float)gk, (float)gp);
+        }
+    tab[NW + NG] = make_float4((float)wf[2 * (WM / 2)], (float)wf[2 * (WM / 2) + 1], (float)g[WM / 2], 0.0f);
+    h.wq_x = tab[NW + NG].x;
+    h.wq_y = tab[NW + NG].y;
+    h.gq = tab[NW + NG].z;
+    OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
+    OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
+    return OFX_OK;
+}
+
+template <int FEAT>
+static int launch_wave(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const WaveTabs& tabs,
+                       const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                       hipStream_t st) {
+    OFX_LDS_ATTR_ONCE((k_wave<FEAT>), sizeof(WaveShared));
+    long long grid = (long long)p->cu_count * WG_PER_CU_W;
+    if (grid * WAVES > n) grid = (n + WAVES - 1) / WAVES;
+    size_t tix = 0;
+    int rc = ofx_time_begin(p, st, &tix);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_wave<FEAT>), dim3((unsigned)grid), dim3(WBLK), sizeof(WaveShared), st, pd, sd,
+                       tabs, d_traces, d_valid, n, d_out);
+    rc = ofx_time_end(p, st, tix);
+    if (rc) return rc;
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+int ofx_wave_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                     hipStream_t st) {
+    int rc = wave_tables(p);
+    if (rc) return rc;
+    OfxPlanDev pd;
+    ofx_fill_plan_dev(p, &pd);
+    struct G { enum { N = WN, ROWS = WROWS, NROWS = 16 }; };
+    fused_classify_windows<G>(pd);
+    WaveTabs tabs;
+    memset(&tabs, 0, sizeof(tabs));
+    tabs.t1 = p->d_tw1;
+    tabs.t2 = p->d_tw2;
+    tabs.tbase = p->d_tw2 + 8 * 16;
+    {
+        // lane 0, slots j >= 8: bin 64 + 128 (j - 8) = 128 j + (64 - 1024): i exp(-2 pi i (64 - 1024) / N) = -t_64
+        const double a = -6.283185307179586476925286766559 * 64.0 / WN;
+        tabs.tb0hi = make_float2((float)-std::cos(a), (float)-std::sin(a));
+    }
+    tabs.midW = reinterpret_cast<const float4*>(p->d_tw1);      // never read without searches
+    tabs.midG = p->d_tw1;
+    OfxSlotDev sd;
+    memset(&sd, 0, sizeof(sd));
+    int nslots = 0;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
+        if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
+        if (++nslots > 1) {
+            ofx_set_error("FUSED engine (%d samples): several filter slots on one plan are not supported "
+                          "(use the LDS or ROCFFT engine)", WN);
+            return OFX_ERR_UNSUPPORTED;
+        }
+        ofx_fill_slot_dev(p, s, &sd);
+        tabs.midW = p->slot[s].d_pq;
+        tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * 64);
+        tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
+        tabs.gq = p->slot[s].gq;
+        for (int q = 0; q < sd.n_search; ++q)
+            if (sd.search[q].nlow > WLOW) {
+                ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", WN,
+                              sd.search[q].nlow, WLOW);
+                return OFX_ERR_UNSUPPORTED;
+            }
+    }
+    if (pd.n_bands > 0) {
+        if (nslots == 0) {
+            ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
+                          "search on the plan (use the ROCFFT engine otherwise)");
+            return OFX_ERR_UNSUPPORTED;
+        }
+        for (int i = 0; i < pd.n_bands; ++i)
+            if (pd.band[i].k_hi > WLOW) {
+                ofx_set_error("FUSED engine (%d samples): band [%d,%d) exceeds the %d stashed bins", WN,
+                              pd.band[i].k_lo, pd.band[i].k_hi, WLOW);
+                return OFX_ERR_UNSUPPORTED;
+            }
+    }
+    int feat = 0;
+    if (pd.n_tdwin > 0) feat |= 2;
+    if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
+    switch (feat) {
+        case 0: return launch_wave<0>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+        case 2: return launch_wave<2>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+        case 4: return launch_wave<4>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+        default: return launch_wave<6>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+    }
+}

@@ -40,7 +40,7 @@ def test_oracle_reproduces_golden(name):
 
 
 def _engines_for(n):
-    return ["fused", "rocfft", "lds"] if n in (32768, 25000) else ["rocfft", "lds"]
+    return ["fused", "rocfft", "lds"] if n in (32768, 25000, 4096) else ["rocfft", "lds"]
 
 
 @pytest.mark.gpu
