@@ -29,6 +29,8 @@
 //
 // Roofline: HBM, 4096 x 4 + 16 B algorithmic per trace (SURVEY.md section 8d at this length).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -65,7 +67,7 @@ struct WaveShared {
 static_assert(sizeof(WaveShared) * WG_PER_CU_W <= 160 * 1024, "LDS budget");
 
 struct WaveTabs {
-    const float2* t1;     // [16][128]  w_2048^{n' k1}
+    const float2* t1;     // [6][64]    w_2048^{a n'}, a = 1, 2, 3, 4, 8, 12: the stage-1 anchors
     const float2* t2;     // [8][16]    w_128^{n3 k2}
     const float4* midW;   // [16][64]   (W_k / 2, conj(W_p) / 2)   slot j, lane v
     const float2* midG;   // [16][64]   (g_k', g_p')
@@ -76,6 +78,13 @@ struct WaveTabs {
 };
 
 #include "ofx_fused_parts.h"
+[[maybe_unused]] constexpr int NWAVE = 1;        // (stamp layout: one wave per "workgroup")
+#include "ofx_fused_stamps.h"
+#ifdef OFX_STAMPS                    // diagnostic build: stamps wait for everything outstanding
+#define WSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); STAMP(i); } while (0)
+#else
+#define WSTAMP(i) STAMP(i)
+#endif
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(a, fmaxf(b, c)); }
 __device__ __forceinline__ float min3f(float a, float b, float c) { return fminf(a, fminf(b, c)); }
 
@@ -92,34 +101,85 @@ __device__ constexpr int wperm_out_src(int j) {
     return j - 8;
 }
 
+// ---- stage-1 twiddles w_2048^{n' k1}: six anchors per lane (k1 = 1, 2, 3 and 4, 8, 12 at n' = lane)
+// live in registers for the whole persistent loop; k1 = a + 4 b is the product of two of them, and the
+// lane's second virtual thread (n' = lane + 64) differs by the constant w_32^{k1}.  No table loads
+// inside the loop: the compiler serialises such loads (load, wait, use, load ...), 30 round trips to
+// L2 per stage in the first version of this kernel (profiles/r03_wave_timeline_v1.json).
+// (the anchors pass through an opaque copy per stage: the nine products are recomputed where they are
+// used instead of being hoisted out of the persistent loop into 18 more live registers)
+__device__ __forceinline__ void t1_opaque(cpx (&A)[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(A[i]));
+}
+template <int K1, bool INV>
+__device__ __forceinline__ void t1_step(cpx (&d)[WNV], const cpx (&A)[6]) {
+    if constexpr (K1 < 16) {
+        constexpr int a = K1 & 3, b = K1 >> 2;
+        cpx w;
+        if constexpr (b == 0) w = A[a - 1];
+        else if constexpr (a == 0) w = A[2 + b];
+        else w = cmul(A[a - 1], A[2 + b]);
+        if constexpr (!INV) {
+            d[K1] = cmul(d[K1], w);
+            d[16 + K1] = twmul<K1, -1>(cmul(d[16 + K1], w));
+        } else {
+            d[K1] = cmulc(d[K1], w);
+            d[16 + K1] = twmul<K1, +1>(cmulc(d[16 + K1], w));
+        }
+        t1_step<K1 + 1, INV>(d, A);
+    }
+}
+
+// ---- the middle step: 16 pair slots per lane, the filter rows requested WMID_DEPTH slots ahead
+#ifndef OFX_WMID_DEPTH
+#define OFX_WMID_DEPTH 8
+#endif
+constexpr int WMID = OFX_WMID_DEPTH;
+template <int J>
+__device__ __forceinline__ void wmid_request(float4 (&tw)[WMID], cpx (&tg)[WMID], __amdgpu_buffer_rsrc_t rw,
+                                             __amdgpu_buffer_rsrc_t rg, int v) {
+    tw[J % WMID] = buf_ld4(rw, v * 16, J * 64 * 16);
+    tg[J % WMID] = buf_ld2(rg, v * 8, J * 64 * 8);
+}
+template <int J>
+__device__ __forceinline__ void wmid_request_first(float4 (&tw)[WMID], cpx (&tg)[WMID], __amdgpu_buffer_rsrc_t rw,
+                                                   __amdgpu_buffer_rsrc_t rg, int v) {
+    if constexpr (J < WMID) {
+        wmid_request<J>(tw, tg, rw, rg, v);
+        wmid_request_first<J + 1>(tw, tg, rw, rg, v);
+    }
+}
 template <int J>
 __device__ __forceinline__ void wmid(cpx (&d)[WNV], __amdgpu_buffer_rsrc_t rw, __amdgpu_buffer_rsrc_t rg,
-                                     int v, WaveLds& L, cpx tlo, cpx thi, cpx& chi) {
+                                     int v, WaveLds& L, cpx tlo, cpx thi, float4 (&tw)[WMID],
+                                     cpx (&tg)[WMID], cpx& chi) {
     if constexpr (J < 16) {
-        // (the tables of the 64 lanes x 16 slots are 24 KB per filter: L1 / L2 resident, and eight
-        // waves per CU hide their latency -- no software pipeline here)
-        const float4 tw = buf_ld4(rw, v * 16, J * 64 * 16);
-        const cpx tg = buf_ld2(rg, v * 8, J * 64 * 8);
+        const float4 w = tw[J % WMID];
+        const cpx g = tg[J % WMID];
+        if constexpr (J + WMID < 16) wmid_request<J + WMID>(tw, tg, rw, rg, v);
         const cpx T = twmul<J, -1>(J < 8 ? tlo : thi);
         cpx xk2, xp2;
-        mid_slot(d[J], d[16 + 15 - J], T, tw, tg, xk2, xp2, chi);
+        mid_slot(d[J], d[16 + 15 - J], T, w, g, xk2, xp2, chi);
         // low bins for lowchi2 / psd_amp: xk2 = 2 X_k, k = v + 128 J; xp2 = 2 conj(X_p),
         // p = 128 (16 - J) - v (v != 0); lane 0's slots 8, 9 hold the bins 64 and 192.  No branch:
         // what does not apply goes to the padding behind the stash.
         if constexpr (J <= 1) L.xlow[v + 128 * J] = xk2;
         if constexpr (J >= 14) L.xlow[v != 0 ? 128 * (16 - J) - v : WLOW + 1] = cconj(xp2);
         if constexpr (J == 8 || J == 9) L.xlow[v == 0 ? 64 + 128 * (J - 8) : WLOW + 2] = xk2;
-        wmid<J + 1>(d, rw, rg, v, L, tlo, thi, chi);
+        wmid<J + 1>(d, rw, rg, v, L, tlo, thi, tw, tg, chi);
     }
 }
 
 // ------------------------------------------------------------------ the kernel
-// FEAT bit 1: time-domain windows; bit 2: channel algebra on load.
+// FEAT bit 0: a windowed / interpolating search (the lags are dumped to LDS); bit 1: time-domain
+// windows; bit 2: channel algebra on load.
 template <int FEAT>
 __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSlotDev sd, WaveTabs tabs,
                                                             const float* __restrict__ traces,
                                                             const uint8_t* __restrict__ valid,
-                                                            long long n_traces, float* __restrict__ out) {
+                                                            long long n_traces, float* __restrict__ out,
+                                                            [[maybe_unused]] unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     WaveShared& SH = *reinterpret_cast<WaveShared*>(smem_raw);
     const int tid = (int)threadIdx.x;
@@ -129,12 +189,8 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
     for (int i = tid; i < 128; i += WBLK) SH.t2[i] = mk(tabs.t2[i].x, tabs.t2[i].y);
     __syncthreads();                    // the only workgroup barrier of the kernel
     const int pre = pd.pre;
-    const __amdgpu_buffer_rsrc_t rt1 = make_rsrc(tabs.t1, 16 * 128 * 8);
-    const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 64 * 8);
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(tabs.midW, 16 * 64 * 16);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(tabs.midG, 16 * 64 * 8);
-    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, WLOW * 8);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, WLOW * 4);
     const size_t ev_stride = (size_t)pd.n_channels * WN;
     cpx* const xc = L.xb;
     float* const xf = reinterpret_cast<float*>(L.xb);
@@ -143,40 +199,99 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
     const int e1r = k1q * 128 + n3;                     // D1 read base: + 4 g * 128 + 16 n2
     const int e2w = k1q * WLD2 + n3;                    // D2 write base: + (4 g + 16 k2) * WLD2
     const int bB = (lane == 0) ? 64 : 128 - lane;       // partner block of this lane
+    // loop-invariant tables of this lane, in registers: stage-1 anchors, T_v, the low-frequency
+    // template / weights of its bins
+    cpx anch[6];
+    {
+        const __amdgpu_buffer_rsrc_t rt1 = make_rsrc(tabs.t1, 6 * 64 * 8);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) anch[i] = buf_ld2(rt1, lane * 8, i * 512);
+    }
+    cpx tb;
+    {
+        const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 64 * 8);
+        tb = buf_ld2(rtb, lane * 8, 0);
+    }
+    const cpx tbh = (lane == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;   // (kernel argument: a select)
+    constexpr int NLK = WLOW / 64;
+    cpx lk_s[NLK];
+    float lk_g[NLK];
+    {
+        const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, WLOW * 8);
+        const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, WLOW * 4);
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            lk_s[i] = mk(0.0f, 0.0f);
+            lk_g[i] = 0.0f;
+            if (sd.n_search > 0) {
+                lk_s[i] = buf_ld2(rs_s, (lane + 64 * i) * 8, 0);
+                lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, (lane + 64 * i) * 4, 0, 0));
+            }
+        }
+    }
+    bool any_full = false;
+    for (int q = 0; q < sd.n_search; ++q) {
+        const OfxSearchDev& sq = sd.search[q];
+        any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 && sq.hi == WN;
+    }
     cpx d[WNV];
-
+#ifdef OFX_STAMPS
+    int stamp_it = 0;
+    unsigned long long* stamp_base = stamps + ((size_t)blockIdx.x * WAVES + wave) * OFX_STAMP_TRACES * 16;
+#endif
+    // The trace of the NEXT iteration is requested as soon as the registers of this one are free (the
+    // tail runs under the loads): the first channel term of the event, raw.
+    auto request = [&](long long bb) {
+        const float* e = traces + (size_t)bb * ev_stride;
+        const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * WN : 0), WN * 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) d[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
+    };
     const long long wstride = (long long)gridDim.x * WAVES;
-    for (long long b = (long long)blockIdx.x * WAVES + wave; b < n_traces; b += wstride) {
+    long long b = (long long)blockIdx.x * WAVES + wave;
+    bool have = b < n_traces;
+    unsigned vcur = 1;
+    if (have) {
+        if (valid) vcur = valid[b];
+        request(b);
+    }
+    while (have) {
+        const long long bnext = b + wstride;
+        const bool have_next = bnext < n_traces;
+        unsigned vnext = 1;
         float* row = out + (size_t)b * pd.row;
-        if (valid && !valid[b]) {                       // wave-uniform
+        const long long bcur = b;
+        b = bnext;
+        have = have_next;
+        if (!vcur) {                                    // wave-uniform
             for (int j = lane; j < pd.row; j += 64) row[j] = OFX_SENTINEL;
+            if (have_next) {
+                if (valid) vnext = valid[bnext];
+                request(bnext);
+            }
+            vcur = vnext;
             continue;
         }
-        // ------------------------------------------------ load (+ channel algebra)
-        {
-            const float* e = traces + (size_t)b * ev_stride;
-            const __amdgpu_buffer_rsrc_t rz =
-                make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * WN : 0), WN * 4);
+        WSTAMP(0);
+        // ------------------------------------------------ channel algebra
+        if constexpr (FEAT & 4) {
+            if (!(pd.n_terms == 1 && pd.weight[0] == 1.0f)) {
+                const float* e = traces + (size_t)bcur * ev_stride;
+                const float w0 = pd.weight[0];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int j = 0; j < WNV; ++j) d[j] = d[j] * mk(w0, w0);
+                for (int c = 1; c < pd.n_terms; ++c) {
+                    const __amdgpu_buffer_rsrc_t rc = make_rsrc(e + (size_t)pd.chan[c] * WN, WN * 4);
+                    const float wgt = pd.weight[c];
 #pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) d[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
-            if constexpr (FEAT & 4) {
-                if (!(pd.n_terms == 1 && pd.weight[0] == 1.0f)) {
-                    const float w0 = pd.weight[0];
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int j = 0; j < WNV; ++j) d[j] = d[j] * mk(w0, w0);
-                    for (int c = 1; c < pd.n_terms; ++c) {
-                        const __amdgpu_buffer_rsrc_t rc = make_rsrc(e + (size_t)pd.chan[c] * WN, WN * 4);
-                        const float wgt = pd.weight[c];
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int n1 = 0; n1 < 16; ++n1) {
-                                const cpx s = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024);
-                                d[16 * h + n1] = pfma(mk(wgt, wgt), s, d[16 * h + n1]);
-                            }
-                    }
+                        for (int n1 = 0; n1 < 16; ++n1) {
+                            const cpx s = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024);
+                            d[16 * h + n1] = pfma(mk(wgt, wgt), s, d[16 * h + n1]);
+                        }
                 }
             }
         }
@@ -221,7 +336,7 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
                 const float MX = ofx_wave_max(mx);
                 const float MN = ofx_wave_min(mn);
                 if (lane == 0) {
-                    const float* e = traces + (size_t)b * ev_stride;
+                    const float* e = traces + (size_t)bcur * ev_stride;
                     float first = 0.f, last = 0.f;
                     if constexpr (FEAT & 4) {
                         for (int c = 0; c < pd.n_terms; ++c) {
@@ -245,15 +360,21 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
                 }
             }
         }
-        if (sd.n_search == 0) continue;
+        if (sd.n_search == 0) {                         // windows only
+            if (have_next) {
+                if (valid) vnext = valid[bnext];
+                request(bnext);
+            }
+            vcur = vnext;
+            continue;
+        }
+        WSTAMP(1);
         // ---------------------------------------------------------------- F1
         dft<16, -1, WNV, 0>(d);
         dft<16, -1, WNV, 16>(d);
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1)
-                d[16 * h + k1] = cmul(d[16 * h + k1], buf_ld2(rt1, (lane + 64 * h) * 8, k1 * 1024));
+        t1_opaque(anch);
+        t1_step<1, false>(d, anch);
+        WSTAMP(2);
         // ---------------------------------------------------------------- E1: D1[k1][n']
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -266,6 +387,7 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
 #pragma unroll
             for (int n2 = 0; n2 < 8; ++n2) d[8 * g + n2] = xc[e1r + 512 * g + 16 * n2];
         __builtin_amdgcn_wave_barrier();
+        WSTAMP(3);
         // ---------------------------------------------------------------- F2
         dft<8, -1, WNV, 0>(d);
         dft<8, -1, WNV, 8>(d);
@@ -275,6 +397,11 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int k2 = 1; k2 < 8; ++k2) d[8 * g + k2] = cmul(d[8 * g + k2], SH.t2[k2 * 16 + n3]);
+        WSTAMP(4);
+        // the filter rows of the first middle slots: requested here, ahead of the exchange and F3
+        float4 mtw[WMID];
+        cpx mtg[WMID];
+        wmid_request_first<0>(mtw, mtg, rw, rg, lane);
         // ---------------------------------------------------------------- E2: D2[k1 + 16 k2][n3]
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -287,9 +414,11 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
             d[16 + j] = xc[bB * WLD2 + j];
         }
         __builtin_amdgcn_wave_barrier();
+        WSTAMP(5);
         // ------------------------------------------- F3, middle, I3 (registers)
         dft<16, -1, WNV, 0>(d);
         dft<16, -1, WNV, 16>(d);
+        WSTAMP(6);
         cpx chi2v = mk(0.0f, 0.0f);
         {
             const cpx a8 = d[8];
@@ -300,9 +429,7 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
 #pragma unroll
                 for (int j = 8; j < 32; ++j) d[j] = L.perm[wperm_in_src(j)];
             }
-            const cpx tb = buf_ld2(rtb, lane * 8, 0);
-            const cpx tbh = (lane == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;   // (kernel argument: a select)
-            wmid<0>(d, rw, rg, lane, L, tb, tbh, chi2v);
+            wmid<0>(d, rw, rg, lane, L, tb, tbh, mtw, mtg, chi2v);
             if (lane == 0) {
                 // self-paired bin k = M/2 (A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
                 const cpx zq = cmulc(a8, mk(tabs.wq.x, tabs.wq.y));
@@ -315,6 +442,7 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
                 d[8] = zq + zq;
             }
         }
+        WSTAMP(7);
         dft<16, +1, WNV, 0>(d);
         dft<16, +1, WNV, 16>(d);
         const float chi0 = ofx_wave_sum(chi2v.x + chi2v.y);
@@ -330,6 +458,7 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
 #pragma unroll
             for (int k2 = 0; k2 < 8; ++k2) d[8 * g + k2] = xc[e2w + (4 * g + 16 * k2) * WLD2];
         __builtin_amdgcn_wave_barrier();
+        WSTAMP(8);
         // ---------------------------------------------------------------- I2
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -350,28 +479,73 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
 #pragma unroll
             for (int k1 = 0; k1 < 16; ++k1) d[16 * h + k1] = xc[k1 * 128 + lane + 64 * h];
         __builtin_amdgcn_wave_barrier();
+        WSTAMP(9);
         // ---------------------------------------------------------------- I1
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int k1 = 1; k1 < 16; ++k1)
-                d[16 * h + k1] = cmulc(d[16 * h + k1], buf_ld2(rt1, (lane + 64 * h) * 8, k1 * 1024));
+        t1_opaque(anch);
+        t1_step<1, true>(d, anch);
         dft<16, +1, WNV, 0>(d);
         dft<16, +1, WNV, 16>(d);
-        // d[16 h + n1] = (A(2 m), A(2 m + 1)), m = 128 n1 + lane + 64 h: the lag dump in natural order
+        // d[16 h + n1] = (A(n), A(n + 1)), lag n = 256 n1 + 2 (lane + 64 h)
+        WSTAMP(10);
+        // ------------------------------------------------------------- tail
+        // full-range fit from the registers: maximum of A^2 per group of 8 register pairs, then the
+        // lane(s) holding the wave's maximum resolve the smallest rolled index among their lags with
+        // A^2 == max (NumPy argmin on the rolled chi2: ties -> first index), one group as a rule
+        OfxCand fullbest = ofx_cand_none();
+        const float a_lag0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(d[0].x)));
+        if (any_full) {
+            constexpr int NG = WNV / 8;
+            float gm[NG];
+            float mloc = 0.0f;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int g = 0; g < NG; ++g) {
+                float m = 0.0f;
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = d[16 * h + n1];
-        __builtin_amdgcn_wave_barrier();
-        // ------------------------------------------------------------- tail: every search scans LDS
-        constexpr int NLK = WLOW / 64;
-        cpx lk_s[NLK];
-        float lk_g[NLK];
+                for (int j = 8 * g; j < 8 * g + 8; ++j) {
+                    const cpx sq = d[j] * d[j];
+                    m = max3f(m, sq.x, sq.y);
+                }
+                gm[g] = m;
+                mloc = fmaxf(mloc, m);
+            }
+            const float Mstar = ofx_wave_max(mloc);
+            if (mloc == Mstar) {
+                // (the lane id comes from an opaque copy: the 64 rolled indices are recomputed here
+                // instead of being hoisted out of the loop and spilled)
+                int lt = lane;
+                asm volatile("" : "+v"(lt));
 #pragma unroll
-        for (int i = 0; i < NLK; ++i) {
-            lk_s[i] = buf_ld2(rs_s, (lane + 64 * i) * 8, 0);
-            lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, (lane + 64 * i) * 4, 0, 0));
+                for (int g = 0; g < NG; ++g) {
+                    if (__builtin_amdgcn_ballot_w64(gm[g] == Mstar) == 0) continue;
+                    const int base = 2 * (lt + 64 * (g / 2)) + pre;
+#pragma unroll
+                    for (int j = 8 * g; j < 8 * g + 8; ++j) {
+                        const int n1 = j & 15;
+                        const cpx v = d[j];
+                        const int i0 = (base + 256 * n1) & (WN - 1);
+                        const int i1 = (base + 256 * n1 + 1) & (WN - 1);
+                        if (v.x * v.x == Mstar && i0 < fullbest.idx) {
+                            fullbest.idx = i0; fullbest.amp = v.x; fullbest.key = Mstar;
+                        }
+                        if (v.y * v.y == Mstar && i1 < fullbest.idx) {
+                            fullbest.idx = i1; fullbest.amp = v.y; fullbest.key = Mstar;
+                        }
+                    }
+                }
+            }
+            fullbest = ofx_cand_wave_reduce(fullbest);
+        }
+        if constexpr (FEAT & 1) {                       // the lag dump, natural order
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = d[16 * h + n1];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the registers are free: the next trace is on its way while the tail runs
+        if (have_next) {
+            if (valid) vnext = valid[bnext];
+            request(bnext);
         }
         // psd_amp bands from the stashed 2 X_k (one band after the other: the wave is the workgroup here)
         if (pd.n_bands > 0) {
@@ -387,17 +561,29 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
                 if (lane == 0) row[pd.band[i].out_off] = acc / (float)(hi - lo);
             }
         }
+        WSTAMP(11);
 #pragma unroll 1
         for (int q = 0; q < sd.n_search; ++q) {
             const OfxSearchDev& sq = sd.search[q];
+            const bool full = !sq.outside && sq.lo == 0 && sq.hi == WN;
             OfxCand best = ofx_cand_none();
             if (sq.kind == OFX_SEARCH_NODELAY) {
-                best.amp = xf[0];
+                best.amp = a_lag0;
                 best.idx = pre;
                 best.key = best.amp * best.amp;
-            } else {
+            } else if (full) {
+                best = fullbest;
+            } else if constexpr (FEAT & 1) {
+                // four independent reads per round (reads past the range stay inside the dump)
                 auto scan = [&](int i0, int i1) {
-                    for (int i = i0 + lane; i < i1; i += 64) ofx_cand_take(best, xf[(i - pre) & (WN - 1)], i);
+                    for (int i = i0 + lane; i < i1; i += 256) {
+                        float a[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) a[u] = xf[(i + 64 * u - pre) & (WN - 1)];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (i + 64 * u < i1) ofx_cand_take(best, a[u], i + 64 * u);
+                    }
                 };
                 if (sq.outside) {
                     scan(0, sq.lo);
@@ -411,10 +597,13 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
             ref.amp = best.amp;
             ref.frac = 0.0f;
             ref.chi2 = 0.0f;
-            const bool refine = sq.interp && best.idx != 0x7fffffff;
-            if (refine)
-                ref = ofx_interpolate(xf[(best.idx - 1 - pre) & (WN - 1)], best.amp,
-                                      xf[(best.idx + 1 - pre) & (WN - 1)], best.idx, WN, sd.norm, chi0);
+            bool refine = false;
+            if constexpr (FEAT & 1) {
+                refine = sq.interp && best.idx != 0x7fffffff;
+                if (refine)
+                    ref = ofx_interpolate(xf[(best.idx - 1 - pre) & (WN - 1)], best.amp,
+                                          xf[(best.idx + 1 - pre) & (WN - 1)], best.idx, WN, sd.norm, chi0);
+            }
             // low-frequency chi2: the lane's bins are 64 apart, the phase runs along a chain
             const int dl = best.idx - pre;
             auto phase_of = [&](int k) {
@@ -443,6 +632,8 @@ __global__ __launch_bounds__(WBLK, WG_PER_CU_W) void k_wave(OfxPlanDev pd, OfxSl
             if (lane == 0) ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, low, refine ? &ref : nullptr);
         }
         __builtin_amdgcn_wave_barrier();            // the dump is read: the next trace may use the buffer
+        WSTAMP(12);
+        vcur = vnext;
     }
 }
 
@@ -453,11 +644,12 @@ bool ofx_wave_supported(int n_samples) { return n_samples == WN; }
 static int wave_tables(ofx_plan* p) {
     if (p->d_tw1) return OFX_OK;
     const double PI2 = 6.283185307179586476925286766559;
-    std::vector<float2> t1(16 * 128), t2(8 * 16 + 64);
-    for (int k1 = 0; k1 < 16; ++k1)
-        for (int n = 0; n < 128; ++n) {
-            const double a = -PI2 * (double)((k1 * n) % WM) / WM;
-            t1[k1 * 128 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+    std::vector<float2> t1(6 * 64), t2(8 * 16 + 64);
+    const int anchor_mult[6] = {1, 2, 3, 4, 8, 12};
+    for (int i = 0; i < 6; ++i)
+        for (int n = 0; n < 64; ++n) {
+            const double a = -PI2 * (double)((anchor_mult[i] * n) % WM) / WM;
+            t1[i * 64 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
     for (int k2 = 0; k2 < 8; ++k2)
         for (int n3 = 0; n3 < 16; ++n3) {
@@ -521,14 +713,26 @@ static int launch_wave(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, 
     OFX_LDS_ATTR_ONCE((k_wave<FEAT>), sizeof(WaveShared));
     long long grid = (long long)p->cu_count * WG_PER_CU_W;
     if (grid * WAVES > n) grid = (n + WAVES - 1) / WAVES;
+    unsigned long long* d_stamps = nullptr;
+#ifdef OFX_STAMPS
+    const size_t stamp_bytes = (size_t)grid * WAVES * OFX_STAMP_TRACES * 16 * sizeof(unsigned long long);
+    if (p->d_fused_xwide) (void)hipFree(p->d_fused_xwide);
+    p->d_fused_xwide = nullptr;
+    OFX_HIP(hipMalloc(&p->d_fused_xwide, stamp_bytes));
+    OFX_HIP(hipMemset(p->d_fused_xwide, 0, stamp_bytes));
+    d_stamps = reinterpret_cast<unsigned long long*>(p->d_fused_xwide);
+#endif
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
     hipLaunchKernelGGL((k_wave<FEAT>), dim3((unsigned)grid), dim3(WBLK), sizeof(WaveShared), st, pd, sd,
-                       tabs, d_traces, d_valid, n, d_out);
+                       tabs, d_traces, d_valid, n, d_out, d_stamps);
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
+#ifdef OFX_STAMPS
+    if (int rcd = fused_dump_stamps(st, d_stamps, stamp_bytes)) return rcd;
+#endif
     return OFX_OK;
 }
 
@@ -588,12 +792,17 @@ int ofx_wave_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
             }
     }
     int feat = 0;
+    for (int q = 0; q < sd.n_search; ++q) {
+        const OfxSearchDev& sq = sd.search[q];
+        const bool full = sq.lo == 0 && sq.hi == WN && !sq.outside;
+        if (sq.kind == OFX_SEARCH_DELAY && (sq.interp || !full)) feat |= 1;
+    }
     if (pd.n_tdwin > 0) feat |= 2;
     if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
     switch (feat) {
-        case 0: return launch_wave<0>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
-        case 2: return launch_wave<2>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
-        case 4: return launch_wave<4>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
-        default: return launch_wave<6>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+#define OFX_CASE(F) case F: return launch_wave<F>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+        OFX_CASE(0) OFX_CASE(1) OFX_CASE(2) OFX_CASE(3) OFX_CASE(4) OFX_CASE(5) OFX_CASE(6)
+#undef OFX_CASE
+        default: return launch_wave<7>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
     }
 }
