@@ -16,16 +16,19 @@
 //   F3    lane v owns the 16-point blocks k_low = v and 128 - v (v = 0: the self-paired 0 and 64)
 //   mid   slot j pairs bin v + 128 j with M - (v + 128 j): unpack, filter, chi2_0, re-pack in one
 //         lane -- the Hermitian-partner layout and lane 0's permutation are those of ofx_fused.hip
-//   I3 / E3 / I2 / E4 / I1  mirror images; then the amplitudes A(n) of all 4096 lags go to LDS in
-//         natural order and every search (no-delay, full range, window, outside a window,
-//         interpolated) scans its rolled range there: 64 lags per lane for a full-range fit
+//   I3 / E3 / I2 / E4 / I1  mirror images; the full-range fit takes its arg-max from the registers
+//         (64 lags per lane; group maxima, then the lane holding the wave's maximum resolves the
+//         smallest rolled index), windowed / interpolating searches scan a dump of the 4096 lags in
+//         LDS (FEAT bit 0)
+//   The next trace is requested into the 64 data registers as soon as the arg-max / dump has read
+//   them: the tail (low-frequency chi2, row write) runs under the HBM latency.
 //
 // What the one-wave geometry buys: NO WORKGROUP BARRIER anywhere -- the four exchanges and the
 // arg-max are wave-synchronous (LDS operations of a wave execute in order; __builtin_amdgcn_
 // wave_barrier only pins the compiler) -- and 8 independent traces in flight per CU (two 4-wave
 // workgroups, 20 KB of LDS per wave) instead of two.  A workgroup's waves share nothing but the
-// 1 KB stage-2 twiddle table.  Several filter slots on one plan are not carried (an AUTO plan runs
-// them on the LDS engine); everything else of the plan is.
+// 1 KB stage-2 twiddle table.  The kernel carries one filter; a plan with several filter slots is one
+// launch per slot (ofx_wave_process).
 //
 // Roofline: HBM, 4096 x 4 + 16 B algorithmic per trace (SURVEY.md section 8d at this length).
 #include <cmath>
@@ -756,27 +759,22 @@ int ofx_wave_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
     }
     tabs.midW = reinterpret_cast<const float4*>(p->d_tw1);      // never read without searches
     tabs.midG = p->d_tw1;
-    OfxSlotDev sd;
-    memset(&sd, 0, sizeof(sd));
-    int nslots = 0;
+    // Validate first (a refused plan must not have launched anything), then one launch per filter
+    // slot with searches: the kernel carries one filter, and at this length a second pass over the
+    // traces (L2 / MALL hits for the most part) costs less than parking the spectrum would.  The
+    // time-domain windows and the bands ride with the first launch.
+    int slots[OFX_MAX_SLOTS], nslots = 0;
     for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
         if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
-        if (++nslots > 1) {
-            ofx_set_error("FUSED engine (%d samples): several filter slots on one plan are not supported "
-                          "(use the LDS or ROCFFT engine)", WN);
-            return OFX_ERR_UNSUPPORTED;
-        }
+        OfxSlotDev sd;
         ofx_fill_slot_dev(p, s, &sd);
-        tabs.midW = p->slot[s].d_pq;
-        tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * 64);
-        tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
-        tabs.gq = p->slot[s].gq;
         for (int q = 0; q < sd.n_search; ++q)
             if (sd.search[q].nlow > WLOW) {
                 ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", WN,
                               sd.search[q].nlow, WLOW);
                 return OFX_ERR_UNSUPPORTED;
             }
+        slots[nslots++] = s;
     }
     if (pd.n_bands > 0) {
         if (nslots == 0) {
@@ -791,18 +789,33 @@ int ofx_wave_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                 return OFX_ERR_UNSUPPORTED;
             }
     }
-    int feat = 0;
-    for (int q = 0; q < sd.n_search; ++q) {
-        const OfxSearchDev& sq = sd.search[q];
-        const bool full = sq.lo == 0 && sq.hi == WN && !sq.outside;
-        if (sq.kind == OFX_SEARCH_DELAY && (sq.interp || !full)) feat |= 1;
-    }
-    if (pd.n_tdwin > 0) feat |= 2;
-    if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
-    switch (feat) {
-#define OFX_CASE(F) case F: return launch_wave<F>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
-        OFX_CASE(0) OFX_CASE(1) OFX_CASE(2) OFX_CASE(3) OFX_CASE(4) OFX_CASE(5) OFX_CASE(6)
+    for (int li = 0; li < (nslots > 0 ? nslots : 1); ++li) {
+        OfxSlotDev sd;
+        memset(&sd, 0, sizeof(sd));
+        if (nslots > 0) {
+            const int s = slots[li];
+            ofx_fill_slot_dev(p, s, &sd);
+            tabs.midW = p->slot[s].d_pq;
+            tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 16 * 64);
+            tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
+            tabs.gq = p->slot[s].gq;
+        }
+        if (li == 1) pd.n_tdwin = pd.n_bands = 0;
+        int feat = 0;
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev& sq = sd.search[q];
+            const bool full = sq.lo == 0 && sq.hi == WN && !sq.outside;
+            if (sq.kind == OFX_SEARCH_DELAY && (sq.interp || !full)) feat |= 1;
+        }
+        if (pd.n_tdwin > 0) feat |= 2;
+        if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
+        switch (feat) {
+#define OFX_CASE(F) case F: rc = launch_wave<F>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            OFX_CASE(0) OFX_CASE(1) OFX_CASE(2) OFX_CASE(3) OFX_CASE(4) OFX_CASE(5) OFX_CASE(6)
 #undef OFX_CASE
-        default: return launch_wave<7>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+            default: rc = launch_wave<7>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+        }
+        if (rc) return rc;
     }
+    return OFX_OK;
 }

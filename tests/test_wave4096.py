@@ -226,8 +226,7 @@ def test_edge_cases_and_fallback():
     assert np.array_equal(out2[[0, 2, 4]].astype(np.float64), out[[0, 2, 4]])
     e = plan.process(torch.empty((0, N), dtype=torch.float32, device="cuda:0"))
     assert tuple(e.shape) == (0, plan.row_floats)
-    # beyond the 256 stashed bins, or several filter slots: AUTO falls back for that call (LDS engine),
-    # FUSED refuses
+    # beyond the 256 stashed bins: AUTO falls back for that call (LDS engine), FUSED refuses
     xs, _, _ = synth.make_traces(9, tmpl, psd, FS, ft.ampres, seed=3)
     x32 = xs.astype(np.float32)
     plan_a, ft, filt, tmpl, psd = _mk(engine="auto")
@@ -239,17 +238,22 @@ def test_edge_cases_and_fallback():
     plan_f.add_search(0, "delay", lowchi2_fcutoff=100000.0)
     with pytest.raises(_lib.OfxError):
         _run(plan_f, x32)
-    plan_m, ft, filt, tmpl, psd = _mk(engine="auto")
+    # several filter slots: one launch per slot
+    plan_m, ft, filt, tmpl, psd = _mk(engine="fused")
     t2 = synth.make_template(N, N // 2, FS, "glitch")
     ft2 = build_filter(t2, psd, FS, N // 2)
     plan_m.set_filter(1, ft2)
     m0, m1 = plan_m.add_search(0, "delay"), plan_m.add_search(1, "delay")
+    wm = plan_m.add_tdwindow(10, 900)
     outm = _run(plan_m, x32)
+    assert plan_m.engine == "fused"
+    assert np.allclose(outm[:, plan_m.tdwindow_offset(wm)], x32[:, 10:900].astype(np.float64).mean(axis=1),
+                       rtol=1e-4, atol=1e-13)
     check_search(outm, plan_m.search_offset(0, m0), orc.process_events(filt, x32.astype(np.float64), "unconstrained"),
-                 "", ft.ampres, FS, "auto/two slots 0")
+                 "", ft.ampres, FS, "two slots 0")
     check_search(outm, plan_m.search_offset(1, m1),
                  orc.process_events(orc.OFFilter(t2, psd, FS, N // 2), x32.astype(np.float64), "unconstrained"),
-                 "", ft2.ampres, FS, "auto/two slots 1")
+                 "", ft2.ampres, FS, "two slots 1")
 
 
 def test_agrees_with_the_lds_engine_at_scale():
@@ -278,7 +282,7 @@ def test_agrees_with_the_lds_engine_at_scale():
     assert np.allclose(a2[same, 0], 2.0 * a[:4096][same, 0], rtol=1e-5, atol=1e-4 * ft.ampres)
 
 
-@pytest.mark.parametrize("feat", [0, 2, 4, 6])
+@pytest.mark.parametrize("feat", range(8))
 def test_every_kernel_instantiation_vs_oracle(feat):
     import torch
     from detprocess_amd import OFPlan
@@ -289,8 +293,9 @@ def test_every_kernel_instantiation_vs_oracle(feat):
     filt = orc.OFFilter(tmpl, psd, FS, pre)
     plan = OFPlan(N, pre, FS, max_batch=64, device=0, engine="fused")
     plan.set_filter(0, ft)
-    ids = [("nodelay", plan.add_search(0, "nodelay")), ("unconstrained", plan.add_search(0, "delay")),
-           ("constrained", plan.add_search(0, "delay", pre - 400, pre + 400))]
+    ids = [("nodelay", plan.add_search(0, "nodelay")), ("unconstrained", plan.add_search(0, "delay"))]
+    if feat & 1:
+        ids.append(("constrained", plan.add_search(0, "delay", pre - 400, pre + 400)))
     wins = [(N // 10, N // 2), (N // 2 - 300, N // 2 + 900)] if feat & 2 else []
     wid = [plan.add_tdwindow(a, b) for a, b in wins]
     nch = 2 if feat & 4 else 1
@@ -314,3 +319,60 @@ def test_every_kernel_instantiation_vs_oracle(feat):
         assert np.allclose(out[:, t_ + 0], orc.baseline(x64, a, b), rtol=1e-4, atol=1e-6 * sc)
         assert np.allclose(out[:, t_ + 2], x64[:, a:b].max(axis=1), rtol=2e-6, atol=1e-7 * sc)
         assert np.allclose(out[:, t_ + 3], x64[:, a:b].min(axis=1), rtol=2e-6, atol=1e-7 * sc)
+
+
+def test_three_slots_windows_bands_and_channel_algebra():
+    """The example YAML's shape: three template tags on one plan (one launch per slot here), windows,
+    bands, a summed channel -- against the oracle, every slot bit-identical to a single-slot plan."""
+    import torch
+    from detprocess_amd import OFPlan
+    pre = N // 2
+    psd = synth.make_psd(N, FS)
+    kinds = ("pulse", "glitch", "muon")
+    tmpls = [synth.make_template(N, pre, FS, k) for k in kinds]
+    fts = [build_filter(t, psd, FS, pre) for t in tmpls]
+    filts = [orc.OFFilter(t, psd, FS, pre) for t in tmpls]
+    plan = OFPlan(N, pre, FS, max_batch=64, device=0, engine="fused")
+    ids = []
+    for s, ft in enumerate(fts):
+        plan.set_filter(s, ft)
+        ids.append((plan.add_search(s, "nodelay", lowchi2_fcutoff=50000.0),
+                    plan.add_search(s, "delay", lowchi2_fcutoff=50000.0),
+                    plan.add_search(s, "delay", pre - 500, pre + 500, interpolate=(s == 1))))
+    wins = [(100, 1500), (0, N - 1), (N // 2 - 500, N // 2 + 263)]
+    wid = [plan.add_tdwindow(a, b) for a, b in wins]
+    bands = [(1, 20), (N // 60, N // 36), (160, 200)]
+    bid = [plan.add_band(a, b) for a, b in bands]
+    ev, _, _ = synth.make_traces(2 * 21, tmpls[0], psd, FS, fts[0].ampres, seed=314)
+    ev = ev.reshape(21, 2, N).astype(np.float32)
+    plan.set_channels(2, [0, 1], [0.75, -1.25])
+    out = plan.process(torch.as_tensor(ev, device="cuda:0")).cpu().numpy().astype(np.float64)
+    assert plan.engine == "fused"
+    x64 = combine_fp32(ev, [0, 1], [0.75, -1.25])
+    for s, (ft, filt) in enumerate(zip(fts, filts)):
+        r_nd = orc.process_events(filt, x64, "nodelay", lowchi2_fcutoff=50000.0)
+        r_un = orc.process_events(filt, x64, "unconstrained", lowchi2_fcutoff=50000.0)
+        r_co = orc.process_events(filt, x64, "constrained", window_min_index=pre - 500,
+                                  window_max_index=pre + 500, interpolate=(s == 1))
+        for j, r in enumerate((r_nd, r_un, r_co)):
+            check_search(out, plan.search_offset(s, ids[s][j]), r, "", ft.ampres, FS, f"{kinds[s]} search {j}",
+                         interpolated=(j == 2 and s == 1), lowchi2_fcutoff=50000.0 if j < 2 else 10000.0)
+    sc = np.abs(x64).max()
+    for i, (a, b) in enumerate(wins):
+        t = plan.tdwindow_offset(wid[i])
+        assert np.allclose(out[:, t + 0], orc.baseline(x64, a, b), rtol=1e-4, atol=1e-6 * sc), (a, b)
+        assert np.allclose(out[:, t + 1], orc.integral(x64, FS, a, b), rtol=1e-4, atol=1e-6 * sc * (b - a) / FS), (a, b)
+    for i, (lo, hi) in enumerate(bands):
+        V = np.fft.rfft(x64, axis=-1)[:, lo:hi] / N
+        want = np.sqrt(2.0 * np.abs(V) ** 2 * N / FS).mean(axis=-1)
+        assert np.allclose(out[:, plan.band_offset(bid[i])], want, rtol=2e-5), (lo, hi)
+    for s, ft in enumerate(fts):
+        solo = OFPlan(N, pre, FS, max_batch=64, device=0, engine="fused")
+        solo.set_filter(0, ft)
+        solo.add_search(0, "nodelay", lowchi2_fcutoff=50000.0)
+        solo.add_search(0, "delay", lowchi2_fcutoff=50000.0)
+        solo.add_search(0, "delay", pre - 500, pre + 500, interpolate=(s == 1))
+        solo.set_channels(2, [0, 1], [0.75, -1.25])
+        so = solo.process(torch.as_tensor(ev, device="cuda:0")).cpu().numpy().astype(np.float64)
+        o0 = plan.search_offset(s, ids[s][0])
+        assert np.array_equal(out[:, o0:o0 + 24], so[:, :24]), f"slot {s} differs from its solo plan"
