@@ -362,7 +362,8 @@ def main():
         if args.config == 1:
             plan.add_search(0, "delay")                       # of1x1_unconstrained
             out_floats = 4
-            what = "of1x1_unconstrained (BASELINE configs[1])"
+            what = "of1x1_unconstrained (BASELINE configs[1]" + ("" if N_SAMPLES == 32768 else
+                                                                 f"'s workload at {N_SAMPLES} samples") + ")"
         else:
             lo, hi = search_range(N_SAMPLES, pre, FS, -400, 400)
             plan.add_search(0, "delay", lo, hi)               # of1x1_constrained +-400 us

@@ -108,7 +108,7 @@ __device__ constexpr int wperm_out_src(int j) {
 // live in registers for the whole persistent loop; k1 = a + 4 b is the product of two of them, and the
 // lane's second virtual thread (n' = lane + 64) differs by the constant w_32^{k1}.  No table loads
 // inside the loop: the compiler serialises such loads (load, wait, use, load ...), 30 round trips to
-// L2 per stage in the first version of this kernel (profiles/r03_wave_timeline_v1.json).
+// L2 per stage in the first version of this kernel (profiles/r03_phase_timeline_4096_first_version.json).
 // (the anchors pass through an opaque copy per stage: the nine products are recomputed where they are
 // used instead of being hoisted out of the persistent loop into 18 more live registers)
 __device__ __forceinline__ void t1_opaque(cpx (&A)[6]) {

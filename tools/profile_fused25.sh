@@ -1,14 +1,19 @@
 #!/bin/bash
-# Profile artefacts of the 25000-sample FUSED kernel (k_fused25) on the GPU box, run from the repo
+# Profile artefacts of a FUSED kernel other than the headline one on the GPU box, run from the repo
 # root through gpurun:  kernel stats of the bench command, separate FETCH_SIZE / WRITE_SIZE passes,
-# SQ counters.  Output: gpurun_out/prof25/ ; tools/make_profiles25.py turns it into profiles/rNN_*.
+# SQ counters.   tools/profile_fused25.sh [samples = 25000] [traces = 1048576]
+# (25000: k_fused25, 4096: k_wave).  Output: gpurun_out/prof<samples>/ (25000: prof25);
+# tools/make_profiles25.py turns it into profiles/rNN_*.
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 export TMPDIR=/tmp
-O=$R/gpurun_out/prof25
+S=${1:-25000}
+T=${2:-1048576}
+O=$R/gpurun_out/prof$S
+[ "$S" = 25000 ] && O=$R/gpurun_out/prof25
 rm -rf $O; mkdir -p $O
 cd $R
-BENCH="python3 bench.py --samples 25000 --config 1"
+BENCH="python3 bench.py --samples $S --traces $T --config 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $BENCH --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1
 echo "stats done"
 for p in FETCH_SIZE WRITE_SIZE; do

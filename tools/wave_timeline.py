@@ -50,8 +50,11 @@ torch.cuda.synchronize()
     total = float((t[:, 1:, 0] - t[:, :-1, 0]).mean())
     rt = a[ok][:, 3:31, 15]
     clk = float(((t[:, -1, 0] - t[:, 0, 0]) / np.maximum(rt[:, -1] - rt[:, 0], 1)).mean() * 100.0)
-    rec = {'kernel': 'k_wave', 'workload': f'4096 samples, workload {wl}', 'n_traces': n,
-           'waves': int(ok.sum()), 'cycles_per_trace_per_wave': total, 'clock_mhz': clk, 'phases': rows,
+    rec = {'kernel': 'k_wave', 'workload': f'config{wl}_n4096', 'n_traces': n,
+           'waves': int(ok.sum()), 'cycles_per_trace_per_wave': total,
+           'clock_mhz': {'mean': clk, 'how': 'd s_memtime / d s_memrealtime x 100 MHz between the stamps 0 of '
+                                               'the traces 3 and 30 of every wave'},
+           'phases': rows,
            'note': 'stamps wait for outstanding memory operations (s_waitcnt 0) -- latencies are exposed'}
     print(json.dumps(rec, indent=1))
     if out:
