@@ -265,7 +265,7 @@ def run_fused(cases, seed, verbose=True, n=32768):
         chans = list(rng.permutation(n_total)[:nterm])
         weights = [1.0] if (nterm == 1 and rng.integers(0, 2)) else list(rng.choice([1.0, -1.0, 0.7, 1.3], nterm))
         x, _, _ = synth.make_traces(B * n_total, tmpls[0], psd, FS, fts[0].ampres, seed=int(rng.integers(1 << 30)),
-                                    max_delay=2000)
+                                    max_delay=min(2000, n // 4))
         ev = x.reshape(B, n_total, n).astype(np.float32)
         valid = (rng.random(B) < 0.9).astype(np.uint8)
         searches = []
@@ -281,7 +281,7 @@ def run_fused(cases, seed, verbose=True, n=32768):
         for _ in range(int(rng.integers(0, 4))):
             lo = int(rng.integers(0, n - 2)); tdw.append((lo, int(rng.integers(lo + 1, n))))
         # beyond 512 bins: the stash (32768 samples); 25000 samples: up to the 1250 bins kept in LDS
-        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, 120000.0 if n == 32768 else 62000.0]))
+        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, {32768: 120000.0, 4096: 70000.0}.get(n, 62000.0)]))
         tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)} fcut={fcut_c}'
         if verbose:
             print('   searches', searches, 'windows', tdw, flush=True)
@@ -439,6 +439,8 @@ if __name__ == '__main__':
         bad = run_fused(cases, seed, n=12500)
     elif len(sys.argv) > 3 and sys.argv[3] == 'fused20':
         bad = run_fused(cases, seed, n=20000)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'wave':          # k_wave, 4096 samples
+        bad = run_fused(cases, seed, n=4096)
     elif len(sys.argv) > 3 and sys.argv[3] == 'adc':
         bad = run_adc(cases, seed)
     else:
