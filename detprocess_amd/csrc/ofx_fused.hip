@@ -1487,44 +1487,9 @@ int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
     if (p->N != FN) return ofx_fused25_prepare_slot(p, slot, wf);
     int rc = fused_tables(p);
     if (rc) return rc;
-    OfxSlotHost& h = p->slot[slot];
-    const std::vector<double>& g = h.g_host;
-    constexpr int NW = 16 * FV, NG = 8 * FV;
-    std::vector<float4> tab(NW + NG + 1);
-    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
-    auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
-    for (int v = 0; v < FV; ++v) {
-        for (int j = 0; j < 16; ++j) {
-            int k;
-            if (v != 0) k = v + 1024 * j;
-            else k = (j < 8) ? 1024 * j : 512 + 1024 * (j - 8);
-            const int pidx = (FM - k) % FM;
-            double wkr, wki, wpr, wpi, gk, gp;
-            if (k == 0) {
-                // slot (DC, Nyquist): "p" is the Nyquist bin N/2 = M
-                W(0, wkr, wki);
-                W(FM, wpr, wpi);
-                gk = g[0] / 4.0;
-                gp = g[FM] / 4.0;
-            } else {
-                W(k, wkr, wki);
-                W(pidx, wpr, wpi);
-                gk = g[k] / 2.0;
-                gp = g[pidx] / 2.0;
-            }
-            tab[j * FV + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0),
-                                          (float)(wpr / 2.0), (float)(-wpi / 2.0));
-            tg[j * FV + v] = make_float2((float)gk, (float)gp);
-        }
-    }
-    tab[NW + NG] = make_float4((float)wf[2 * (FM / 2)], (float)wf[2 * (FM / 2) + 1],
-                               (float)g[FM / 2], 0.0f);
-    h.wq_x = tab[NW + NG].x;
-    h.wq_y = tab[NW + NG].y;
-    h.gq = tab[NW + NG].z;
-    OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
-    OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
-    return OFX_OK;
+    return fused_build_slot_tables(p, slot, wf, FM, FV, FV, 16, [](int v, int j) {
+        return v != 0 ? v + 1024 * j : (j < 8 ? 1024 * j : 512 + 1024 * (j - 8));
+    });
 }
 
 template <int FEAT, bool MULTI>
@@ -1649,46 +1614,13 @@ int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
 }
 
 // ---- the transform on its own (rows of 16384 complex points; used by the N x M engine)
-struct RegFft32 {
-    float2* d_t1 = nullptr;
-    float2* d_t2 = nullptr;
-    int cu_count = 256;
-};
 int ofx_fused_fft_create(int n_complex, int device, void** out) {
     if (n_complex != FM || VT != 2 || PP) return OFX_ERR_UNSUPPORTED;
-    ofx_plan tmp;                       // only its table pointers are used
-    int rc = fused_tables(&tmp);
-    if (rc) return rc;
-    RegFft32* f = new RegFft32();
-    f->d_t1 = tmp.d_tw1;
-    f->d_t2 = tmp.d_tw2;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) f->cu_count = prop.multiProcessorCount;
-    *out = f;
-    return OFX_OK;
+    return fused_fft_create(device, out, fused_tables);
 }
-void ofx_fused_fft_destroy(void* h) {
-    RegFft32* f = static_cast<RegFft32*>(h);
-    if (!f) return;
-    if (f->d_t1) (void)hipFree(f->d_t1);
-    if (f->d_t2) (void)hipFree(f->d_t2);
-    delete f;
-}
+void ofx_fused_fft_destroy(void* h) { fused_fft_destroy(h); }
 int ofx_fused_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,
                        hipStream_t st) {
-    RegFft32* f = static_cast<RegFft32*>(h);
-    if (rows <= 0) return OFX_OK;
-    long long grid = (long long)f->cu_count * WG_PER_CU;
-    if (grid > rows) grid = rows;
-    if (forward) {
-        OFX_LDS_ATTR_ONCE((k_fft32<true>), sizeof(FusedShared));
-        hipLaunchKernelGGL((k_fft32<true>), dim3((unsigned)grid), dim3(FT), sizeof(FusedShared), st,
-                           f->d_t1, f->d_t2, in, out, rows);
-    } else {
-        OFX_LDS_ATTR_ONCE((k_fft32<false>), sizeof(FusedShared));
-        hipLaunchKernelGGL((k_fft32<false>), dim3((unsigned)grid), dim3(FT), sizeof(FusedShared), st,
-                           f->d_t1, f->d_t2, in, out, rows);
-    }
-    OFX_HIP(hipGetLastError());
-    return OFX_OK;
+    return fused_fft_exec<&k_fft32<true>, &k_fft32<false>>(h, forward, in, out, rows, st, WG_PER_CU, FT,
+                                                           sizeof(FusedShared));
 }

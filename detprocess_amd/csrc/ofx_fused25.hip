@@ -1292,43 +1292,9 @@ static int fused25_tables(ofx_plan* p) {
 int OFX25_FN(prepare_slot)(ofx_plan* p, int slot, const double* wf) {
     int rc = fused25_tables(p);
     if (rc) return rc;
-    OfxSlotHost& h = p->slot[slot];
-    const std::vector<double>& g = h.g_host;
-    constexpr int NW = R3 * VPAD, NG = R3 * VPAD / 2;
-    std::vector<float4> tab(NW + NG + 1, make_float4(0.f, 0.f, 0.f, 0.f));
-    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
-    auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
-    for (int v = 0; v < GT; ++v) {
-        for (int j = 0; j < R3; ++j) {
-            int k;
-            if (v != 0) k = v + GP * j;
-            else k = (j <= 12) ? GP * j : GP / 2 + GP * (j - 13);
-            const int pidx = (GM - k) % GM;
-            double wkr, wki, wpr, wpi, gk, gp;
-            if (k == 0) {
-                W(0, wkr, wki);
-                W(GM, wpr, wpi);
-                gk = g[0] / 4.0;
-                gp = g[GM] / 4.0;
-            } else {
-                W(k, wkr, wki);
-                W(pidx, wpr, wpi);
-                gk = g[k] / 2.0;
-                gp = g[pidx] / 2.0;
-            }
-            tab[j * VPAD + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0),
-                                            (float)(wpr / 2.0), (float)(-wpi / 2.0));
-            tg[j * VPAD + v] = make_float2((float)gk, (float)gp);
-        }
-    }
-    tab[NW + NG] = make_float4((float)wf[2 * (GM / 2)], (float)wf[2 * (GM / 2) + 1],
-                               (float)g[GM / 2], 0.0f);
-    h.wq_x = tab[NW + NG].x;
-    h.wq_y = tab[NW + NG].y;
-    h.gq = tab[NW + NG].z;
-    OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
-    OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
-    return OFX_OK;
+    return fused_build_slot_tables(p, slot, wf, GM, GT, VPAD, R3, [](int v, int j) {
+        return v != 0 ? v + GP * j : (j <= 12 ? GP * j : GP / 2 + GP * (j - 13));
+    });
 }
 
 template <int FEAT, bool MULTI>
@@ -1423,46 +1389,13 @@ int OFX25_FN(process)(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
 }
 
 // ---- the transform on its own (ofx_ldsfft_* dispatch to these for GM-point rows)
-struct RegFft25 {
-    float2* d_t1 = nullptr;
-    float2* d_t2 = nullptr;
-    int cu_count = 256;
-};
 int OFX25_FN(fft_create)(int n_complex, int device, void** out) {
     if (n_complex != GM) return OFX_ERR_UNSUPPORTED;
-    ofx_plan tmp;                       // only its table pointers are used
-    int rc = fused25_tables(&tmp);
-    if (rc) return rc;
-    RegFft25* f = new RegFft25();
-    f->d_t1 = tmp.d_tw1;
-    f->d_t2 = tmp.d_tw2;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) f->cu_count = prop.multiProcessorCount;
-    *out = f;
-    return OFX_OK;
+    return fused_fft_create(device, out, fused25_tables);
 }
-void OFX25_FN(fft_destroy)(void* h) {
-    RegFft25* f = static_cast<RegFft25*>(h);
-    if (!f) return;
-    if (f->d_t1) (void)hipFree(f->d_t1);
-    if (f->d_t2) (void)hipFree(f->d_t2);
-    delete f;
-}
+void OFX25_FN(fft_destroy)(void* h) { fused_fft_destroy(h); }
 int OFX25_FN(fft_exec)(void* h, bool forward, const float2* in, float2* out, long long rows,
                        hipStream_t st) {
-    RegFft25* f = static_cast<RegFft25*>(h);
-    if (rows <= 0) return OFX_OK;
-    long long grid = (long long)f->cu_count * WG_PER_CU;
-    if (grid > rows) grid = rows;
-    if (forward) {
-        OFX_LDS_ATTR_ONCE((k_fft25<true>), sizeof(Shared25));
-        hipLaunchKernelGGL((k_fft25<true>), dim3((unsigned)grid), dim3(BLK), sizeof(Shared25), st,
-                           f->d_t1, f->d_t2, in, out, rows);
-    } else {
-        OFX_LDS_ATTR_ONCE((k_fft25<false>), sizeof(Shared25));
-        hipLaunchKernelGGL((k_fft25<false>), dim3((unsigned)grid), dim3(BLK), sizeof(Shared25), st,
-                           f->d_t1, f->d_t2, in, out, rows);
-    }
-    OFX_HIP(hipGetLastError());
-    return OFX_OK;
+    return fused_fft_exec<&k_fft25<true>, &k_fft25<false>>(h, forward, in, out, rows, st, WG_PER_CU, BLK,
+                                                           sizeof(Shared25));
 }

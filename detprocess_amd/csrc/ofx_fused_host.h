@@ -149,6 +149,96 @@ static int fused_upload_tables(ofx_plan* p, const std::vector<float2>& t1, const
     return OFX_OK;
 }
 
+// Middle-step tables of one filter slot from the fp64 one-sided filter, the same recipe in every
+// register-resident kernel: thread (lane) v, pair slot j holds the bin k = bin_of(v, j) and its partner
+// M - k (k = 0 pairs DC with Nyquist).
+//   d_pq (float4 units): [0 .. nslot * vpad)        midW (W_k / 2, conj(W_p) / 2)   [slot j][v]
+//                        [nslot * vpad .. + half)   midG (g_k', g_p') as float2      [slot j][v]
+//                        last entry                 (W_{M/2}.x, W_{M/2}.y, g_{M/2}, 0): the self-paired bin
+template <class BinOf>
+static int fused_build_slot_tables(ofx_plan* p, int slot, const double* wf, int M, int nthreads, int vpad,
+                                   int nslot, BinOf bin_of) {
+    OfxSlotHost& h = p->slot[slot];
+    const std::vector<double>& g = h.g_host;
+    const int NW = nslot * vpad, NG = nslot * vpad / 2;
+    std::vector<float4> tab(NW + NG + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
+    auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
+    for (int v = 0; v < nthreads; ++v) {
+        for (int j = 0; j < nslot; ++j) {
+            const int k = bin_of(v, j);
+            const int pidx = (M - k) % M;
+            double wkr, wki, wpr, wpi, gk, gp;
+            if (k == 0) {                   // slot (DC, Nyquist): "p" is the Nyquist bin N/2 = M
+                W(0, wkr, wki);
+                W(M, wpr, wpi);
+                gk = g[0] / 4.0;
+                gp = g[M] / 4.0;
+            } else {
+                W(k, wkr, wki);
+                W(pidx, wpr, wpi);
+                gk = g[k] / 2.0;
+                gp = g[pidx] / 2.0;
+            }
+            tab[j * vpad + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0), (float)(wpr / 2.0),
+                                            (float)(-wpi / 2.0));
+            tg[j * vpad + v] = make_float2((float)gk, (float)gp);
+        }
+    }
+    tab[NW + NG] = make_float4((float)wf[2 * (M / 2)], (float)wf[2 * (M / 2) + 1], (float)g[M / 2], 0.0f);
+    h.wq_x = tab[NW + NG].x;
+    h.wq_y = tab[NW + NG].y;
+    h.gq = tab[NW + NG].z;
+    OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
+    OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
+    return OFX_OK;
+}
+
+// The transform of a kernel on its own (rows of M complex points; the N x M engine runs on these): a handle
+// with the twiddle tables, and the launch of the forward / inverse kernel.
+struct FusedRegFft {
+    float2* d_t1 = nullptr;
+    float2* d_t2 = nullptr;
+    int cu_count = 256;
+};
+template <class Tables>
+[[maybe_unused]] static int fused_fft_create(int device, void** out, Tables tables) {
+    ofx_plan tmp;                       // only its table pointers are used
+    int rc = tables(&tmp);
+    if (rc) return rc;
+    FusedRegFft* f = new FusedRegFft();
+    f->d_t1 = tmp.d_tw1;
+    f->d_t2 = tmp.d_tw2;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) f->cu_count = prop.multiProcessorCount;
+    *out = f;
+    return OFX_OK;
+}
+[[maybe_unused]] static void fused_fft_destroy(void* h) {
+    FusedRegFft* f = static_cast<FusedRegFft*>(h);
+    if (!f) return;
+    if (f->d_t1) (void)hipFree(f->d_t1);
+    if (f->d_t2) (void)hipFree(f->d_t2);
+    delete f;
+}
+template <auto KFWD, auto KINV>
+[[maybe_unused]] static int fused_fft_exec(void* h, bool forward, const float2* in, float2* out, long long rows,
+                                           hipStream_t st, int wg_per_cu, int threads, size_t lds_bytes) {
+    FusedRegFft* f = static_cast<FusedRegFft*>(h);
+    if (rows <= 0) return OFX_OK;
+    long long grid = (long long)f->cu_count * wg_per_cu;
+    if (grid > rows) grid = rows;
+    if (forward) {
+        OFX_LDS_ATTR_ONCE(*KFWD, lds_bytes);
+        hipLaunchKernelGGL(KFWD, dim3((unsigned)grid), dim3(threads), lds_bytes, st, f->d_t1, f->d_t2, in, out, rows);
+    } else {
+        OFX_LDS_ATTR_ONCE(*KINV, lds_bytes);
+        hipLaunchKernelGGL(KINV, dim3((unsigned)grid), dim3(threads), lds_bytes, st, f->d_t1, f->d_t2, in, out, rows);
+    }
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
 // -DOFX_STAMPS builds: the stamps of the launch that just ran go to $OFX_STAMP_FILE
 // (tools/phase_timeline.py, tools/dev_tail_timeline.py read it).
 [[maybe_unused]] static int fused_dump_stamps(hipStream_t st, const void* d_stamps, size_t stamp_bytes) {

@@ -672,41 +672,9 @@ static int wave_tables(ofx_plan* p) {
 int ofx_wave_prepare_slot(ofx_plan* p, int slot, const double* wf) {
     int rc = wave_tables(p);
     if (rc) return rc;
-    OfxSlotHost& h = p->slot[slot];
-    const std::vector<double>& g = h.g_host;
-    constexpr int NW = 16 * 64, NG = 8 * 64;
-    std::vector<float4> tab(NW + NG + 1);
-    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
-    auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
-    for (int v = 0; v < 64; ++v)
-        for (int j = 0; j < 16; ++j) {
-            int k;
-            if (v != 0) k = v + 128 * j;
-            else k = (j < 8) ? 128 * j : 64 + 128 * (j - 8);
-            const int pidx = (WM - k) % WM;
-            double wkr, wki, wpr, wpi, gk, gp;
-            if (k == 0) {                   // slot (DC, Nyquist): "p" is the Nyquist bin N/2 = M
-                W(0, wkr, wki);
-                W(WM, wpr, wpi);
-                gk = g[0] / 4.0;
-                gp = g[WM] / 4.0;
-            } else {
-                W(k, wkr, wki);
-                W(pidx, wpr, wpi);
-                gk = g[k] / 2.0;
-                gp = g[pidx] / 2.0;
-            }
-            tab[j * 64 + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0), (float)(wpr / 2.0),
-                                          (float)(-wpi / 2.0));
-            tg[j * 64 + v] = make_float2((float)gk, (float)gp);
-        }
-    tab[NW + NG] = make_float4((float)wf[2 * (WM / 2)], (float)wf[2 * (WM / 2) + 1], (float)g[WM / 2], 0.0f);
-    h.wq_x = tab[NW + NG].x;
-    h.wq_y = tab[NW + NG].y;
-    h.gq = tab[NW + NG].z;
-    OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
-    OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
-    return OFX_OK;
+    return fused_build_slot_tables(p, slot, wf, WM, 64, 64, 16, [](int v, int j) {
+        return v != 0 ? v + 128 * j : (j < 8 ? 128 * j : 64 + 128 * (j - 8));
+    });
 }
 
 template <int FEAT>
