@@ -63,6 +63,6 @@ if __name__ == '__main__':
                      'max(|amp|, ampres)',
            'n32768': report(32768, ('fused', 'rocfft'), B),
            'n25000': report(25000, ('fused', 'lds', 'rocfft'), B // 2),
-           'n4096': report(4096, ('lds', 'rocfft'), B)}
+           'n4096': report(4096, ('fused', 'lds', 'rocfft'), B)}
     json.dump(rep, open(dest, 'w'), indent=1)
     print('written', dest)
