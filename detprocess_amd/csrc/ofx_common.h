@@ -246,6 +246,11 @@ bool ofx_wave_supported(int n_samples);
 int ofx_wave_prepare_slot(ofx_plan* p, int slot, const double* wf);
 int ofx_wave_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
                      float* d_out, hipStream_t st);
+// ofx_wave2.hip: two waves per trace, 8192-sample traces
+bool ofx_wave2_supported(int n_samples);
+int ofx_wave2_prepare_slot(ofx_plan* p, int slot, const double* wf);
+int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
+                      float* d_out, hipStream_t st);
 bool ofx_lds_supported(int n_samples);
 int ofx_lds_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid,
                     long long n, float* d_out, hipStream_t st);

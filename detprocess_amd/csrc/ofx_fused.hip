@@ -1433,7 +1433,8 @@ bool ofx_fused_supported(int n_samples) {
     return n_samples == FN || ofx_fused25_supported(n_samples) ||   // 25000: ofx_fused25.hip
            ofx_fused12_supported(n_samples) ||                      // 12500: ofx_fused12.hip
            ofx_fused20_supported(n_samples) ||                      // 20000: ofx_fused20.hip
-           ofx_wave_supported(n_samples);                           // 4096: ofx_wave.hip
+           ofx_wave_supported(n_samples) ||                         // 4096: ofx_wave.hip
+           ofx_wave2_supported(n_samples);                          // 8192: ofx_wave2.hip
 }
 
 int ofx_fused_release(ofx_plan* p) {
@@ -1482,6 +1483,7 @@ static int fused_tables(ofx_plan* p) {
 // j < 8 and 512 + 1024 (j - 8) above; k = 0 pairs DC with Nyquist).
 int ofx_fused_prepare_slot(ofx_plan* p, int slot, const double* wf) {
     if (ofx_wave_supported(p->N)) return ofx_wave_prepare_slot(p, slot, wf);
+    if (ofx_wave2_supported(p->N)) return ofx_wave2_prepare_slot(p, slot, wf);
     if (ofx_fused12_supported(p->N)) return ofx_fused12_prepare_slot(p, slot, wf);
     if (ofx_fused20_supported(p->N)) return ofx_fused20_prepare_slot(p, slot, wf);
     if (p->N != FN) return ofx_fused25_prepare_slot(p, slot, wf);
@@ -1580,6 +1582,7 @@ static int launch_feat(int feat, ofx_plan* p, const OfxPlanDev& pd, const OfxSlo
 int ofx_fused_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n,
                       float* d_out, hipStream_t st) {
     if (ofx_wave_supported(p->N)) return ofx_wave_process(p, d_traces, d_valid, n, d_out, st);
+    if (ofx_wave2_supported(p->N)) return ofx_wave2_process(p, d_traces, d_valid, n, d_out, st);
     if (ofx_fused12_supported(p->N)) return ofx_fused12_process(p, d_traces, d_valid, n, d_out, st);
     if (ofx_fused20_supported(p->N)) return ofx_fused20_process(p, d_traces, d_valid, n, d_out, st);
     if (p->N != FN) return ofx_fused25_process(p, d_traces, d_valid, n, d_out, st);

@@ -156,13 +156,8 @@ static int fused_upload_tables(ofx_plan* p, const std::vector<float2>& t1, const
 //                        [nslot * vpad .. + half)   midG (g_k', g_p') as float2      [slot j][v]
 //                        last entry                 (W_{M/2}.x, W_{M/2}.y, g_{M/2}, 0): the self-paired bin
 template <class BinOf>
-static int fused_build_slot_tables(ofx_plan* p, int slot, const double* wf, int M, int nthreads, int vpad,
-                                   int nslot, BinOf bin_of) {
-    OfxSlotHost& h = p->slot[slot];
-    const std::vector<double>& g = h.g_host;
-    const int NW = nslot * vpad, NG = nslot * vpad / 2;
-    std::vector<float4> tab(NW + NG + 1, make_float4(0.f, 0.f, 0.f, 0.f));
-    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
+static void fused_fill_slot_tables(float4* tw, float2* tg, const double* wf, const std::vector<double>& g, int M,
+                                   int nthreads, int vpad, int nslot, BinOf bin_of) {
     auto W = [&](int k, double& re, double& im) { re = wf[2 * k]; im = wf[2 * k + 1]; };
     for (int v = 0; v < nthreads; ++v) {
         for (int j = 0; j < nslot; ++j) {
@@ -180,18 +175,32 @@ static int fused_build_slot_tables(ofx_plan* p, int slot, const double* wf, int 
                 gk = g[k] / 2.0;
                 gp = g[pidx] / 2.0;
             }
-            tab[j * vpad + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0), (float)(wpr / 2.0),
-                                            (float)(-wpi / 2.0));
+            tw[j * vpad + v] = make_float4((float)(wkr / 2.0), (float)(wki / 2.0), (float)(wpr / 2.0),
+                                           (float)(-wpi / 2.0));
             tg[j * vpad + v] = make_float2((float)gk, (float)gp);
         }
     }
-    tab[NW + NG] = make_float4((float)wf[2 * (M / 2)], (float)wf[2 * (M / 2) + 1], (float)g[M / 2], 0.0f);
-    h.wq_x = tab[NW + NG].x;
-    h.wq_y = tab[NW + NG].y;
-    h.gq = tab[NW + NG].z;
+}
+// ... the table of the self-paired bin M / 2 behind them, and the upload
+static int fused_finish_slot_tables(ofx_plan* p, int slot, const double* wf, std::vector<float4>& tab, int M) {
+    OfxSlotHost& h = p->slot[slot];
+    const std::vector<double>& g = h.g_host;
+    tab.back() = make_float4((float)wf[2 * (M / 2)], (float)wf[2 * (M / 2) + 1], (float)g[M / 2], 0.0f);
+    h.wq_x = tab.back().x;
+    h.wq_y = tab.back().y;
+    h.gq = tab.back().z;
     OFX_HIP(hipMalloc(&h.d_pq, sizeof(float4) * tab.size()));
     OFX_HIP(hipMemcpy(h.d_pq, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice));
     return OFX_OK;
+}
+template <class BinOf>
+static int fused_build_slot_tables(ofx_plan* p, int slot, const double* wf, int M, int nthreads, int vpad,
+                                   int nslot, BinOf bin_of) {
+    const int NW = nslot * vpad, NG = nslot * vpad / 2;
+    std::vector<float4> tab(NW + NG + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    fused_fill_slot_tables(tab.data(), reinterpret_cast<float2*>(tab.data() + NW), wf, p->slot[slot].g_host, M,
+                           nthreads, vpad, nslot, bin_of);
+    return fused_finish_slot_tables(p, slot, wf, tab, M);
 }
 
 // The transform of a kernel on its own (rows of M complex points; the N x M engine runs on these): a handle

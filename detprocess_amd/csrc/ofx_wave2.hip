@@ -1,0 +1,779 @@
+// ofx_wave2.hip -- FUSED engine at 8192 samples: TWO WAVES PER TRACE.
+//
+// Path: FeatureExtractors.of1x1_nodelay / _unconstrained / _constrained + baseline / integral /
+// maximum / minimum / psd_amp on 8192-sample traces (detprocess/core/algorithms.py:277-570, 650-885,
+// 952-1044; processing_data.py:712-772), as ofx_wave.hip does at 4096 samples.
+//
+// The packed transform has M' = 4096 complex points; it is split once, decimation in frequency, into two
+// 2048-point transforms -- exactly the transform a wave of ofx_wave.hip runs in its registers:
+//
+//   y_s[m] = (z[m] + (-1)^s z[m + 2048]) w_4096^{m s},  s = 0, 1      X[2 q + s] = FFT_2048(y_s)[q]
+//
+// Wave s of the workgroup loads BOTH halves of the trace (the second read of a line is an L2 hit), forms y_s
+// in its registers and owns the bins of parity s from there on: F1 / E1 / F2 / E2 / F3 of ofx_wave_parts.h,
+// no workgroup barrier, no exchange with the other wave.  The Hermitian partner of bin 2 q + s is
+// M' - (2 q + s) = 2 (2048 - q) [s = 0] or 2 (2047 - q) + 1 [s = 1]: the SAME parity, so the pairwise
+// middle step stays inside the wave as well (even wave: the layout of k_wave, DC / Nyquist and the
+// self-paired bin M'/2 in lane 0; odd wave: blocks v and 127 - v, nothing self-paired).  The inverse mirrors
+// the forward; only then do the waves meet:
+//
+//   A(2 m + e), A(4096 + 2 m + e) = Re / Im of  y'_0[m] +- conj(w_4096^m) y'_1[m]
+//
+// through each other's exchange buffer (one barrier of two waves), after which wave s holds the lags of
+// half s.  Arg-max candidates, chi2_0, the window sums and the low-frequency chi2 are partial per wave and
+// meet in a few words of LDS; wave 0 writes the row.  Four workgroups per CU: eight waves, four traces in
+// flight.  The next trace is requested into the 128 registers of the two raw halves as soon as the lags
+// have been reduced / dumped.
+//
+// Roofline: HBM, 8192 x 4 + 16 B algorithmic per trace.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "ofx_common.h"
+#include "ofx_device.h"
+#include "ofx_fft_regs.h"
+#include "ofx_fused_host.h"
+
+using namespace ofxfft;
+
+namespace {
+
+constexpr int VN = 8192;            // samples
+constexpr int VM = 4096;            // packed complex points = 2 x WM
+constexpr int VBLK = 128;           // two waves: one trace per workgroup
+constexpr int VWG_PER_CU = 4;
+
+#include "ofx_wave_parts.h"
+
+struct Wave2X {                     // what the two waves of a trace tell each other (double-buffered by parity)
+    float chi[2];
+    float lag0;
+    OfxCand cand[2];
+    float td[OFX_MAX_TDWIN][4][2];
+    float lowp[OFX_MAX_SEARCHES][2];
+    float band[OFX_MAX_BANDS][2];
+};
+struct Wave2Shared {
+    WaveLds w[2];
+    Wave2X x[2];
+};
+static_assert(sizeof(Wave2Shared) * VWG_PER_CU <= 160 * 1024, "LDS budget");
+constexpr int LDS_WAVE_FLOATS = sizeof(WaveLds) / 4;      // from w[0].xb to w[1].xb, in floats
+
+struct Wave2Tabs {
+    const float2* t1;     // [6][64]     w_2048^{a n'}, a = 1, 2, 3, 4, 8, 12: the stage-1 anchors
+    const float2* t2;     // [8][16]     w_128^{n3 k2}: seven per lane, kept in registers
+    const float2* ua;     // [64]        w_4096^{n}: the split twiddle (x w_64 for n' >= 64, x w_32^{n1} per row)
+    const float2* tbase;  // [2][64]     T(v, s) = i exp(-2 pi i (2 v + s) / N); slot j: T w_32^j
+    const float4* midW;   // [2][16][64] (W_k / 2, conj(W_p) / 2), k = 2 (v + 128 j) + s
+    const float2* midG;   // [2][16][64] (g_k', g_p')
+    float2 tb0hi;         // even wave, lane 0, slots j >= 8 (block 64)
+    float2 wq;            // W_{M'/2}
+    float gq;             // g_{M'/2}
+};
+
+constexpr float kC64 = 0.99518472667219688624f;     // cos(2 pi / 64)
+constexpr float kS64 = 0.09801714032956060199f;     // sin(2 pi / 64)
+
+// the split twiddle of the odd wave, forward (INV = false: x w_4096^m) and back (x conj)
+template <int N1, bool INV>
+__device__ __forceinline__ void split_tw(cpx (&d)[WNV], cpx u0, cpx u1) {
+    if constexpr (N1 < 16) {
+        if constexpr (!INV) {
+            d[N1] = twmul<N1, -1>(cmul(d[N1], u0));
+            d[16 + N1] = twmul<N1, -1>(cmul(d[16 + N1], u1));
+        } else {
+            d[N1] = twmul<N1, +1>(cmulc(d[N1], u0));
+            d[16 + N1] = twmul<N1, +1>(cmulc(d[16 + N1], u1));
+        }
+        split_tw<N1 + 1, INV>(d, u0, u1);
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+// FEAT bit 0: a windowed / interpolating search (the lags are dumped to LDS); bit 1: time-domain
+// windows; bit 2: channel algebra on load.
+template <int FEAT>
+__global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd, Wave2Tabs tabs,
+                                                   const float* __restrict__ traces,
+                                                   const uint8_t* __restrict__ valid, long long n_traces,
+                                                   float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Wave2Shared& SH = *reinterpret_cast<Wave2Shared*>(smem_raw);
+    const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
+    const int s = __builtin_amdgcn_readfirstlane(tid >> 6);       // parity of this wave's bins / its half of the lags
+    WaveLds& L = SH.w[s];
+    WaveLds& LO = SH.w[s ^ 1];
+    const int pre = pd.pre;
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(tabs.midW + s * 16 * 64, 16 * 64 * 16);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(tabs.midG + s * 16 * 64, 16 * 64 * 8);
+    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, 2 * WLOW * 8);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, 2 * WLOW * 4);
+    const size_t ev_stride = (size_t)pd.n_channels * VN;
+    cpx* const xc = L.xb;
+    const float* const xf0 = reinterpret_cast<const float*>(SH.w[0].xb);      // the dump: lag n at
+                                                                              // xf0[(n >> 12) LDS_WAVE_FLOATS + (n & 4095)]
+    // roles of this lane (loop-invariant, few)
+    const int k1q = lane >> 4, n3 = lane & 15;          // F2: k1 = k1q + 4 g
+    const int e1r = k1q * 128 + n3;                     // D1 read base: + 4 g * 128 + 16 n2
+    const int e2w = k1q * WLD2 + n3;                    // D2 write base: + (4 g + 16 k2) * WLD2
+    const int bB = s ? 127 - lane : (lane == 0 ? 64 : 128 - lane);     // partner block of this lane
+    // loop-invariant tables of this lane, in registers
+    cpx anch[6], t2r[7];
+    {
+        const __amdgpu_buffer_rsrc_t rt1 = make_rsrc(tabs.t1, 6 * 64 * 8);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) anch[i] = buf_ld2(rt1, lane * 8, i * 512);
+        const __amdgpu_buffer_rsrc_t rt2 = make_rsrc(tabs.t2, 128 * 8);
+#pragma unroll
+        for (int k2 = 1; k2 < 8; ++k2) t2r[k2 - 1] = buf_ld2(rt2, n3 * 8, k2 * 128);
+    }
+    cpx tb, u0;
+    {
+        const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 128 * 8);
+        tb = buf_ld2(rtb, lane * 8, s * 512);
+        const __amdgpu_buffer_rsrc_t rua = make_rsrc(tabs.ua, 64 * 8);
+        u0 = buf_ld2(rua, lane * 8, 0);
+    }
+    const cpx tbh = (s == 0 && lane == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
+    bool any_full = false;
+    for (int q = 0; q < sd.n_search; ++q) {
+        const OfxSearchDev& sq = sd.search[q];
+        any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 && sq.hi == VN;
+    }
+    cpx a[WNV], bq[WNV];            // the raw halves z[m], z[m + 2048], m = 128 n1 + lane + 64 h
+    cpx d[WNV];
+    auto request = [&](long long bb) {
+        const float* e = traces + (size_t)bb * ev_stride;
+        const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0), VN * 4);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) {
+                a[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
+                bq[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + 16384);
+            }
+    };
+    long long b = (long long)blockIdx.x;
+    bool have = b < n_traces;
+    unsigned vcur = 1;
+    int par = 0;
+    if (have) {
+        if (valid) vcur = valid[b];
+        request(b);
+    }
+    while (have) {
+        const long long bnext = b + (long long)gridDim.x;
+        const bool have_next = bnext < n_traces;
+        unsigned vnext = 1;
+        float* row = out + (size_t)b * pd.row;
+        const long long bcur = b;
+        b = bnext;
+        have = have_next;
+        if (!vcur) {                                    // uniform over the workgroup
+            for (int j = tid; j < pd.row; j += VBLK) row[j] = OFX_SENTINEL;
+            if (have_next) {
+                if (valid) vnext = valid[bnext];
+                request(bnext);
+            }
+            vcur = vnext;
+            continue;
+        }
+        par ^= 1;
+        Wave2X& X = SH.x[par];
+        // ------------------------------------------------ channel algebra
+        if constexpr (FEAT & 4) {
+            if (!(pd.n_terms == 1 && pd.weight[0] == 1.0f)) {
+                const float* e = traces + (size_t)bcur * ev_stride;
+                const float w0 = pd.weight[0];
+#pragma unroll
+                for (int j = 0; j < WNV; ++j) {
+                    a[j] = a[j] * mk(w0, w0);
+                    bq[j] = bq[j] * mk(w0, w0);
+                }
+                for (int c = 1; c < pd.n_terms; ++c) {
+                    const __amdgpu_buffer_rsrc_t rc = make_rsrc(e + (size_t)pd.chan[c] * VN, VN * 4);
+                    const float wgt = pd.weight[c];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int n1 = 0; n1 < 16; ++n1) {
+                            const cpx za = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024);
+                            const cpx zb = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024 + 16384);
+                            a[16 * h + n1] = pfma(mk(wgt, wgt), za, a[16 * h + n1]);
+                            bq[16 * h + n1] = pfma(mk(wgt, wgt), zb, bq[16 * h + n1]);
+                        }
+                }
+            }
+        }
+        // ------------------------------------------------ time-domain windows
+        // wave s sums over its half of the samples: index 4096 s + 256 n1 + 2 (lane + 64 h) + {0, 1}, rows
+        // 16 s + n1 of the host's classification; the partial sums meet in X.td
+        if constexpr (FEAT & 2) {
+            for (int w = 0; w < pd.n_tdwin; ++w) {
+                const int lo = pd.tdw[w].lo - 4096 * s, hi = pd.tdw[w].hi - 4096 * s;
+                float sm = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
+                cpx s2 = mk(0.0f, 0.0f), sq2 = mk(0.0f, 0.0f);
+                const unsigned fullm = pd.tdw[w].full >> (16 * s), anym = fullm | (pd.tdw[w].edge >> (16 * s));
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    if (!((anym >> n1) & 1u)) continue;                   // uniform: outside
+                    if ((fullm >> n1) & 1u) {                             // uniform: full row
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const cpx v = s ? bq[16 * h + n1] : a[16 * h + n1];
+                            s2 = s2 + v;
+                            sq2 = pfma(v, v, sq2);
+                            mx = max3f(mx, v.x, v.y);
+                            mn = min3f(mn, v.x, v.y);
+                        }
+                    } else {                                              // edge row
+                        const int lo_r = lo - WROWS * n1, hi_r = hi - WROWS * n1;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int c = 2 * (lane + 64 * h);
+                            const bool in0 = (c >= lo_r) && (c < hi_r);
+                            const bool in1 = (c >= lo_r - 1) && (c < hi_r - 1);
+                            const cpx v = s ? bq[16 * h + n1] : a[16 * h + n1];
+                            const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
+                            sm = (sm + y0) + y1;
+                            sq = fmaf(y0, y0, fmaf(y1, y1, sq));
+                            mx = max3f(mx, in0 ? v.x : -INFINITY, in1 ? v.y : -INFINITY);
+                            mn = min3f(mn, in0 ? v.x : INFINITY, in1 ? v.y : INFINITY);
+                        }
+                    }
+                }
+                const float S = ofx_wave_sum(sm + (s2.x + s2.y));
+                const float SQ = ofx_wave_sum(sq + (sq2.x + sq2.y));
+                const float MX = ofx_wave_max(mx);
+                const float MN = ofx_wave_min(mn);
+                if (lane == 0) {
+                    X.td[w][0][s] = S;
+                    X.td[w][1][s] = MX;
+                    X.td[w][2][s] = MN;
+                    X.td[w][3][s] = SQ;
+                }
+            }
+        }
+        // one lane of wave 0 per window: both partials, the end points, the eight values
+        auto td_finalize = [&]() {
+            if constexpr (FEAT & 2) {
+                if (s == 0 && lane < pd.n_tdwin) {
+                    const int w = lane;
+                    const int lo = pd.tdw[w].lo, hi = pd.tdw[w].hi;
+                    const float* e = traces + (size_t)bcur * ev_stride;
+                    float first = 0.f, last = 0.f;
+                    if constexpr (FEAT & 4) {
+                        for (int c = 0; c < pd.n_terms; ++c) {
+                            const float* z = e + (size_t)pd.chan[c] * VN;
+                            first = fmaf(pd.weight[c], z[lo], first);
+                            last = fmaf(pd.weight[c], z[hi - 1], last);
+                        }
+                    } else {
+                        first = e[lo];
+                        last = e[hi - 1];
+                    }
+                    const float S = X.td[w][0][0] + X.td[w][0][1];
+                    float* o = row + pd.tdw[w].out_off;
+                    o[OFX_TD_BASELINE] = S / (float)(hi - lo);
+                    o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
+                    o[OFX_TD_MAXIMUM] = fmaxf(X.td[w][1][0], X.td[w][1][1]);
+                    o[OFX_TD_MINIMUM] = fminf(X.td[w][2][0], X.td[w][2][1]);
+                    o[OFX_TD_SUM] = S;
+                    o[OFX_TD_SUMSQ] = X.td[w][3][0] + X.td[w][3][1];
+                    o[OFX_TD_FIRST] = first;
+                    o[OFX_TD_LAST] = last;
+                }
+            }
+        };
+        if (sd.n_search == 0) {                         // windows only
+            __syncthreads();
+            td_finalize();
+            if (have_next) {
+                if (valid) vnext = valid[bnext];
+                request(bnext);
+            }
+            vcur = vnext;
+            continue;
+        }
+        // ---------------------------------------------------------------- the split: y_s
+        if (s == 0) {
+#pragma unroll
+            for (int j = 0; j < WNV; ++j) d[j] = a[j] + bq[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < WNV; ++j) d[j] = a[j] - bq[j];
+            cpx uu = u0;
+            asm volatile("" : "+v"(uu));                // (no hoisting of the 32 row twiddles out of the loop)
+            split_tw<0, false>(d, uu, cmul(uu, mk(kC64, -kS64)));
+        }
+        // ---------------------------------------------------------------- F1
+        dft<16, -1, WNV, 0>(d);
+        dft<16, -1, WNV, 16>(d);
+        t1_opaque(anch);
+        t1_step<1, false>(d, anch);
+        // ---------------------------------------------------------------- E1: D1[k1][n']
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) xc[k1 * 128 + lane + 64 * h] = d[16 * h + k1];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) d[8 * g + n2] = xc[e1r + 512 * g + 16 * n2];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- F2
+        dft<8, -1, WNV, 0>(d);
+        dft<8, -1, WNV, 8>(d);
+        dft<8, -1, WNV, 16>(d);
+        dft<8, -1, WNV, 24>(d);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 1; k2 < 8; ++k2) d[8 * g + k2] = cmul(d[8 * g + k2], t2r[k2 - 1]);
+        // the filter rows of the first middle slots: requested here, ahead of the exchange and F3
+        float4 mtw[WMID];
+        cpx mtg[WMID];
+        wmid_request_first<0>(mtw, mtg, rw, rg, lane);
+        // ---------------------------------------------------------------- E2: D2[k1 + 16 k2][n3]
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) xc[e2w + (4 * g + 16 * k2) * WLD2] = d[8 * g + k2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            d[j] = xc[lane * WLD2 + j];
+            d[16 + j] = xc[bB * WLD2 + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ------------------------------------------- F3, middle, I3 (registers)
+        dft<16, -1, WNV, 0>(d);
+        dft<16, -1, WNV, 16>(d);
+        cpx chi2v = mk(0.0f, 0.0f);
+        {
+            int lm = lane;
+            cpx tlo = tb, thi = tbh;
+            asm volatile("" : "+v"(lm), "+v"(tlo), "+v"(thi));
+            if (s == 0) {
+                const cpx a8 = d[8];
+                if (lane == 0) {                        // lane 0: blocks 0 and 64 to the slot shape
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) L.perm[j] = d[j];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 8; j < 32; ++j) d[j] = L.perm[wperm_in_src(j)];
+                }
+                wmid<0, 0>(d, rw, rg, lm, L, tlo, thi, mtw, mtg, chi2v);
+                if (lane == 0) {
+                    // self-paired bin k = M'/2 (A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
+                    const cpx zq = cmulc(a8, mk(tabs.wq.x, tabs.wq.y));
+                    chi2v = pfma(a8 * a8, mk(2.0f * tabs.gq, 2.0f * tabs.gq), chi2v);
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) L.perm[j] = d[j];
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 9; j < 32; ++j) d[j] = L.perm[wperm_out_src(j)];
+                    d[8] = zq + zq;
+                }
+            } else {
+                wmid<0, 1>(d, rw, rg, lm, L, tlo, thi, mtw, mtg, chi2v);
+            }
+        }
+        dft<16, +1, WNV, 0>(d);
+        dft<16, +1, WNV, 16>(d);
+        const float chi_w = ofx_wave_sum(chi2v.x + chi2v.y);
+        // ---------------------------------------------------------------- E3
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            xc[lane * WLD2 + j] = d[j];
+            xc[bB * WLD2 + j] = d[16 + j];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 0; k2 < 8; ++k2) d[8 * g + k2] = xc[e2w + (4 * g + 16 * k2) * WLD2];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- I2
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k2 = 1; k2 < 8; ++k2) d[8 * g + k2] = cmulc(d[8 * g + k2], t2r[k2 - 1]);
+        dft<8, +1, WNV, 0>(d);
+        dft<8, +1, WNV, 8>(d);
+        dft<8, +1, WNV, 16>(d);
+        dft<8, +1, WNV, 24>(d);
+        // ---------------------------------------------------------------- E4
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int n2 = 0; n2 < 8; ++n2) xc[e1r + 512 * g + 16 * n2] = d[8 * g + n2];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) d[16 * h + k1] = xc[k1 * 128 + lane + 64 * h];
+        __builtin_amdgcn_wave_barrier();
+        // ---------------------------------------------------------------- I1
+        t1_opaque(anch);
+        t1_step<1, true>(d, anch);
+        dft<16, +1, WNV, 0>(d);
+        dft<16, +1, WNV, 16>(d);
+        // d[16 h + n1] = y'_s[m], m = 128 n1 + lane + 64 h
+        // ---------------------------------------------------------------- the two halves meet
+        if (s == 1) {
+            cpx uu = u0;
+            asm volatile("" : "+v"(uu));
+            split_tw<0, true>(d, uu, cmul(uu, mk(kC64, -kS64)));
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = d[16 * h + n1];
+        if (lane == 0) X.chi[s] = chi_w;
+        __syncthreads();                                // B1: both y' are in LDS
+        {
+            const cpx* const xo = LO.xb;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const cpx o = xo[128 * n1 + lane + 64 * h];
+                    d[16 * h + n1] = s ? o - d[16 * h + n1] : d[16 * h + n1] + o;
+                }
+        }
+        // d[16 h + n1] = (A(n), A(n + 1)), lag n = 4096 s + 256 n1 + 2 (lane + 64 h)
+        __syncthreads();                                // B2: the exchange buffers are free again
+        // ------------------------------------------------------------- tail
+        int lt = lane;
+        asm volatile("" : "+v"(lt));
+        constexpr int NLK = WLOW / 64;
+        cpx lk_s[NLK];
+        float lk_g[NLK];
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {                 // this wave's low bins: k = 2 (lane + 64 i) + s
+            lk_s[i] = buf_ld2(rs_s, (2 * (lt + 64 * i) + s) * 8, 0);
+            lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, (2 * (lt + 64 * i) + s) * 4, 0, 0));
+        }
+        OfxCand mybest = ofx_cand_none();
+        if (s == 0 && lane == 0) X.lag0 = d[0].x;
+        if (any_full) {
+            constexpr int NG = WNV / 8;
+            float gm[NG];
+            float mloc = 0.0f;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float m = 0.0f;
+#pragma unroll
+                for (int j = 8 * g; j < 8 * g + 8; ++j) {
+                    const cpx sq = d[j] * d[j];
+                    m = max3f(m, sq.x, sq.y);
+                }
+                gm[g] = m;
+                mloc = fmaxf(mloc, m);
+            }
+            const float Mstar = ofx_wave_max(mloc);
+            if (mloc == Mstar) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (__builtin_amdgcn_ballot_w64(gm[g] == Mstar) == 0) continue;
+                    const int base = 2 * (lt + 64 * (g / 2)) + pre + 4096 * s;
+#pragma unroll
+                    for (int j = 8 * g; j < 8 * g + 8; ++j) {
+                        const int n1 = j & 15;
+                        const cpx v = d[j];
+                        const int i0 = (base + 256 * n1) & (VN - 1);
+                        const int i1 = (base + 256 * n1 + 1) & (VN - 1);
+                        if (v.x * v.x == Mstar && i0 < mybest.idx) {
+                            mybest.idx = i0; mybest.amp = v.x; mybest.key = Mstar;
+                        }
+                        if (v.y * v.y == Mstar && i1 < mybest.idx) {
+                            mybest.idx = i1; mybest.amp = v.y; mybest.key = Mstar;
+                        }
+                    }
+                }
+            }
+            mybest = ofx_cand_wave_reduce(mybest);
+        }
+        if (lane == 0) X.cand[s] = mybest;
+        if constexpr (FEAT & 1) {                       // the lag dump: this wave's half, natural order
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lt + 64 * h] = d[16 * h + n1];
+        }
+        // the registers are free: the next trace is on its way while the tail runs (requested without a
+        // condition -- the last trace of a workgroup reads itself again --: a conditional request would
+        // keep the 128 registers of the two halves alive through the whole body)
+        {
+            const long long bq_ = have_next ? bnext : bcur;
+            if (valid) vnext = valid[bq_];
+            request(bq_);
+        }
+        // psd_amp bands: this wave's bins (k of its parity), partial sums
+        if (pd.n_bands > 0) {
+            const float cpsd = 0.25f / ((float)VN * pd.fs);
+            for (int i = 0; i < pd.n_bands; ++i) {
+                const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
+                float acc = 0.0f;
+                for (int k = lo + lt; k < hi; k += 64) {
+                    if ((k & 1) == s) {
+                        const cpx x2 = L.xlow[k >> 1];
+                        acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
+                    }
+                }
+                acc = ofx_wave_sum(acc);
+                if (lane == 0) X.band[i][s] = acc;
+            }
+        }
+        __syncthreads();                                // B3: chi2_0, candidates, lag 0, window and band partials, dump
+        const float chi0 = X.chi[0] + X.chi[1];
+        OfxCand fullbest = X.cand[0];
+        {
+            const OfxCand c1 = X.cand[1];
+            if (ofx_cand_better(c1.key, c1.idx, fullbest)) fullbest = c1;
+        }
+        const float a_lag0 = X.lag0;
+        td_finalize();
+        if (s == 0 && lane == 0)
+            for (int i = 0; i < pd.n_bands; ++i)
+                row[pd.band[i].out_off] = (X.band[i][0] + X.band[i][1]) / (float)(pd.band[i].k_hi - pd.band[i].k_lo);
+#pragma unroll 1
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev& sq = sd.search[q];
+            const bool full = !sq.outside && sq.lo == 0 && sq.hi == VN;
+            OfxCand best = ofx_cand_none();
+            if (sq.kind == OFX_SEARCH_NODELAY) {
+                best.amp = a_lag0;
+                best.idx = pre;
+                best.key = best.amp * best.amp;
+            } else if (full) {
+                best = fullbest;
+            } else if constexpr (FEAT & 1) {
+                // both waves scan the whole range (the dump of either half is readable by both): the same
+                // winner in both, nothing to combine
+                auto lagv = [&](int i) {
+                    const int n = (i - pre) & (VN - 1);
+                    return xf0[(n >> 12) * LDS_WAVE_FLOATS + (n & 4095)];
+                };
+                auto scan = [&](int i0, int i1) {
+                    for (int i = i0 + lt; i < i1; i += 256) {
+                        float v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) v[u] = lagv(i + 64 * u);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (i + 64 * u < i1) ofx_cand_take(best, v[u], i + 64 * u);
+                    }
+                };
+                if (sq.outside) {
+                    scan(0, sq.lo);
+                    scan(sq.hi, VN);
+                } else {
+                    scan(sq.lo, sq.hi);
+                }
+                best = ofx_cand_wave_reduce(best);
+            }
+            OfxRefined ref;
+            ref.amp = best.amp;
+            ref.frac = 0.0f;
+            ref.chi2 = 0.0f;
+            bool refine = false;
+            if constexpr (FEAT & 1) {
+                refine = sq.interp && best.idx != 0x7fffffff;
+                if (refine) {
+                    const int nm = (best.idx - 1 - pre) & (VN - 1), np = (best.idx + 1 - pre) & (VN - 1);
+                    ref = ofx_interpolate(xf0[(nm >> 12) * LDS_WAVE_FLOATS + (nm & 4095)], best.amp,
+                                          xf0[(np >> 12) * LDS_WAVE_FLOATS + (np & 4095)], best.idx, VN, sd.norm,
+                                          chi0);
+                }
+            }
+            // low-frequency chi2: this wave's bins k = 2 (lane + 64 i) + s, the phase along a chain
+            const int dl = best.idx - pre;
+            auto phase_of = [&](int k) {
+                const int m = (int)(((unsigned)k * (unsigned)dl) & (unsigned)(VN - 1));
+                float sn, cs;
+                sincospif(-2.0f * ((float)m + (float)k * ref.frac) / (float)VN, &sn, &cs);
+                return mk(cs, sn);
+            };
+            cpx ph = phase_of(2 * lt + s);
+            const cpx step = phase_of(128);
+            float low = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NLK; ++i) {
+                const int k = 2 * (lt + 64 * i) + s;
+                if (k < sq.nlow) {
+                    const cpx x2 = L.xlow[lt + 64 * i];
+                    const float pr = ph.x * lk_s[i].x - ph.y * lk_s[i].y;
+                    const float pi = ph.x * lk_s[i].y + ph.y * lk_s[i].x;
+                    const float rr = 0.5f * x2.x - ref.amp * pr;
+                    const float ri = 0.5f * x2.y - ref.amp * pi;
+                    low += ((k == 0) ? 1.0f : 2.0f) * lk_g[i] * (rr * rr + ri * ri);
+                }
+                ph = cmul(ph, step);
+            }
+            low = ofx_wave_sum(low);
+            if (lane == 0) X.lowp[q][s] = low;
+            __syncthreads();                            // the two partial sums; the scans of the dump are done
+            if (s == 0 && lane == 0)
+                ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, X.lowp[q][0] + X.lowp[q][1],
+                                 refine ? &ref : nullptr);
+        }
+        vcur = vnext;
+    }
+}
+
+}  // namespace
+
+bool ofx_wave2_supported(int n_samples) { return n_samples == VN; }
+
+static int wave2_tables(ofx_plan* p) {
+    if (p->d_tw1) return OFX_OK;
+    const double PI2 = 6.283185307179586476925286766559;
+    std::vector<float2> t1(6 * 64), t2(128 + 64 + 128);
+    const int anchor_mult[6] = {1, 2, 3, 4, 8, 12};
+    for (int i = 0; i < 6; ++i)
+        for (int n = 0; n < 64; ++n) {
+            const double a = -PI2 * (double)((anchor_mult[i] * n) % WM) / WM;
+            t1[i * 64 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int k2 = 0; k2 < 8; ++k2)
+        for (int n3 = 0; n3 < 16; ++n3) {
+            const double a = -PI2 * (double)((k2 * n3) % 128) / 128.0;
+            t2[k2 * 16 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int n = 0; n < 64; ++n) {          // ua[n] = w_4096^n
+        const double a = -PI2 * (double)n / VM;
+        t2[128 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int s = 0; s < 2; ++s)
+        for (int v = 0; v < 64; ++v) {      // tbase[s][v] = i exp(-2 pi i (2 v + s) / N)
+            const double a = -PI2 * (double)(2 * v + s) / VN;
+            t2[192 + 64 * s + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
+        }
+    return fused_upload_tables(p, t1, t2);
+}
+
+// Middle-step tables of one slot: per wave s the rows of ofx_wave.hip at the global bins k = 2 q + s,
+// q = v + 128 j (even wave, lane 0: 128 j for j < 8, 64 + 128 (j - 8) above), partner M' - k.
+//   d_pq (float4 units): [s][16][64] midW, then [s][16][64] midG as float2, last entry the self-paired bin.
+int ofx_wave2_prepare_slot(ofx_plan* p, int slot, const double* wf) {
+    int rc = wave2_tables(p);
+    if (rc) return rc;
+    constexpr int NW = 2 * 16 * 64, NG = NW / 2;
+    std::vector<float4> tab(NW + NG + 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
+    for (int s = 0; s < 2; ++s)
+        fused_fill_slot_tables(tab.data() + s * 16 * 64, tg + s * 16 * 64, wf, p->slot[slot].g_host, VM, 64, 64, 16,
+                               [s](int v, int j) {
+                                   const int q = (s == 1 || v != 0) ? v + 128 * j
+                                                                    : (j < 8 ? 128 * j : 64 + 128 * (j - 8));
+                                   return 2 * q + s;
+                               });
+    return fused_finish_slot_tables(p, slot, wf, tab, VM);
+}
+
+template <int FEAT>
+static int launch_wave2(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const Wave2Tabs& tabs,
+                        const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                        hipStream_t st) {
+    OFX_LDS_ATTR_ONCE((k_wave2<FEAT>), sizeof(Wave2Shared));
+    long long grid = (long long)p->cu_count * VWG_PER_CU;
+    if (grid > n) grid = n;
+    size_t tix = 0;
+    int rc = ofx_time_begin(p, st, &tix);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_wave2<FEAT>), dim3((unsigned)grid), dim3(VBLK), sizeof(Wave2Shared), st, pd, sd, tabs,
+                       d_traces, d_valid, n, d_out);
+    rc = ofx_time_end(p, st, tix);
+    if (rc) return rc;
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                      hipStream_t st) {
+    int rc = wave2_tables(p);
+    if (rc) return rc;
+    OfxPlanDev pd;
+    ofx_fill_plan_dev(p, &pd);
+    struct G { enum { N = VN, ROWS = WROWS, NROWS = 32 }; };
+    fused_classify_windows<G>(pd);
+    Wave2Tabs tabs;
+    memset(&tabs, 0, sizeof(tabs));
+    tabs.t1 = p->d_tw1;
+    tabs.t2 = p->d_tw2;
+    tabs.ua = p->d_tw2 + 128;
+    tabs.tbase = p->d_tw2 + 192;
+    {
+        // even wave, lane 0, slots j >= 8: bin 2 (64 + 128 (j - 8)) = 256 j + (128 - 2048):
+        // i exp(-2 pi i (128 - 2048) / N) = -exp(-2 pi i 128 / N)
+        const double a = -6.283185307179586476925286766559 * 128.0 / VN;
+        tabs.tb0hi = make_float2((float)-std::cos(a), (float)-std::sin(a));
+    }
+    tabs.midW = reinterpret_cast<const float4*>(p->d_tw1);      // never read without searches
+    tabs.midG = p->d_tw1;
+    // Validate first, then one launch per filter slot with searches (as ofx_wave_process).
+    int slots[OFX_MAX_SLOTS], nslots = 0;
+    for (int s = 0; s < OFX_MAX_SLOTS; ++s) {
+        if (!p->slot[s].set || p->slot[s].searches.empty()) continue;
+        OfxSlotDev sd;
+        ofx_fill_slot_dev(p, s, &sd);
+        for (int q = 0; q < sd.n_search; ++q)
+            if (sd.search[q].nlow > 2 * WLOW) {
+                ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", VN,
+                              sd.search[q].nlow, 2 * WLOW);
+                return OFX_ERR_UNSUPPORTED;
+            }
+        slots[nslots++] = s;
+    }
+    if (pd.n_bands > 0) {
+        if (nslots == 0) {
+            ofx_set_error("FUSED engine: psd_amp bands need at least one filter slot with a "
+                          "search on the plan (use the ROCFFT engine otherwise)");
+            return OFX_ERR_UNSUPPORTED;
+        }
+        for (int i = 0; i < pd.n_bands; ++i)
+            if (pd.band[i].k_hi > 2 * WLOW) {
+                ofx_set_error("FUSED engine (%d samples): band [%d,%d) exceeds the %d stashed bins", VN,
+                              pd.band[i].k_lo, pd.band[i].k_hi, 2 * WLOW);
+                return OFX_ERR_UNSUPPORTED;
+            }
+    }
+    for (int li = 0; li < (nslots > 0 ? nslots : 1); ++li) {
+        OfxSlotDev sd;
+        memset(&sd, 0, sizeof(sd));
+        if (nslots > 0) {
+            const int s = slots[li];
+            ofx_fill_slot_dev(p, s, &sd);
+            tabs.midW = p->slot[s].d_pq;
+            tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 2 * 16 * 64);
+            tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
+            tabs.gq = p->slot[s].gq;
+        }
+        if (li == 1) pd.n_tdwin = pd.n_bands = 0;
+        int feat = 0;
+        for (int q = 0; q < sd.n_search; ++q) {
+            const OfxSearchDev& sq = sd.search[q];
+            const bool full = sq.lo == 0 && sq.hi == VN && !sq.outside;
+            if (sq.kind == OFX_SEARCH_DELAY && (sq.interp || !full)) feat |= 1;
+        }
+        if (pd.n_tdwin > 0) feat |= 2;
+        if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
+        switch (feat) {
+#define OFX_CASE(F) case F: rc = launch_wave2<F>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+            OFX_CASE(0) OFX_CASE(1) OFX_CASE(2) OFX_CASE(3) OFX_CASE(4) OFX_CASE(5) OFX_CASE(6)
+#undef OFX_CASE
+            default: rc = launch_wave2<7>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+        }
+        if (rc) return rc;
+    }
+    return OFX_OK;
+}

@@ -1,6 +1,7 @@
 """GPU parity tests of the one-wave-per-trace kernel for 4096-sample traces (BASELINE configs[0]'s
 trace length; detprocess_amd/csrc/ofx_wave.hip): k_wave through the C ABI against the fp64 oracle,
-and the LDS engine on the same inputs (the golden fixtures of this length: tests/test_golden.py)."""
+and the LDS engine on the same inputs (the golden fixtures of this length: tests/test_golden.py).
+Every test also runs at 8192 samples: the two-waves-per-trace kernel k_wave2 (ofx_wave2.hip)."""
 import numpy as np
 import pytest
 
@@ -11,6 +12,14 @@ from util import check_search, combine_fp32
 pytestmark = pytest.mark.gpu
 FS = 1.25e6
 N = 4096
+
+
+@pytest.fixture(autouse=True, params=[4096, 8192])
+def _trace_length(request):
+    global N
+    N = request.param
+    yield
+    N = 4096
 
 
 def _mk(pre=None, engine="fused", max_batch=64):
@@ -49,7 +58,7 @@ def test_unconstrained_vs_oracle(B):
 def test_every_lag_wins():
     """A noiseless template shifted to EVERY lag of the trace: every lane, register and component of
     the lag dump, both ends of the rolled range."""
-    plan, ft, filt, tmpl, psd = _mk(max_batch=4096)
+    plan, ft, filt, tmpl, psd = _mk(max_batch=8192)
     sid = plan.add_search(0, "delay")
     lags = np.arange(-N // 2, N // 2)
     x = np.stack([3e-7 * np.roll(tmpl, int(d)) for d in lags]).astype(np.float32)
@@ -155,7 +164,7 @@ def test_windows_bands_and_channel_algebra():
     ids = (plan.add_search(0, "nodelay", lowchi2_fcutoff=50000.0), plan.add_search(0, "delay", lowchi2_fcutoff=50000.0),
            plan.add_search(0, "delay", pre - 500, pre + 500, interpolate=True))
     wins = [(100, 1500), (0, N - 1), (N // 2 - 500, N // 2 + 263), (256, 512), (255, 513), (1, 2), (4095, 4096),
-            (0, N)]
+            (0, N), (N // 2 - 1, N // 2 + 1), (N - 1, N)][:8 if N == 4096 else 10][-8:]
     wid = [plan.add_tdwindow(a, b) for a, b in wins]
     bands = [(1, 20), (N // 60, N // 36), (200, 256)]
     bid = [plan.add_band(a, b) for a, b in bands]

@@ -446,7 +446,10 @@ def waitcnt_scan(path):
             is_lds = op.startswith("ds_")
             is_smem = op.startswith(("s_load_", "s_buffer_load_", "s_store_", "s_memtime", "s_memrealtime", "s_dcache", "s_atc"))
             if is_vm:
-                vm = {r: (v[0] + 1, v[1], v[2]) for r, v in vm.items()}
+                # (vmcnt is a 6-bit counter: the 64th outstanding operation cannot issue before the oldest
+                # has returned, and loads return in order -- a load with 63 younger operations behind it
+                # has completed, which is what the compiler's own wait insertion relies on)
+                vm = {r: (v[0] + 1, v[1], v[2]) for r, v in vm.items() if v[0] + 1 < 63}
                 if "lds" not in " ".join(ops).split():
                     for r in d:
                         if r[0] == "v":
