@@ -46,6 +46,9 @@ constexpr int VM = 4096;            // packed complex points = 2 x WM
 constexpr int VBLK = 128;           // two waves: one trace per workgroup
 constexpr int VWG_PER_CU = 4;
 
+#ifndef OFX_WMID_DEPTH
+#define OFX_WMID_DEPTH 4            // (8 in k_wave: here the two raw halves of the next trace need the registers)
+#endif
 #include "ofx_wave_parts.h"
 
 struct Wave2X {                     // what the two waves of a trace tell each other (double-buffered by parity)
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
         // ------------------------------------------------ time-domain windows
         // wave s sums over its half of the samples: index 4096 s + 256 n1 + 2 (lane + 64 h) + {0, 1}, rows
         // 16 s + n1 of the host's classification; the partial sums meet in X.td
-        if constexpr (FEAT & 2) {
+        [[maybe_unused]] auto td_sums = [&](const cpx (&z)[WNV]) {
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo - 4096 * s, hi = pd.tdw[w].hi - 4096 * s;
                 float sm = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                     if ((fullm >> n1) & 1u) {                             // uniform: full row
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const cpx v = s ? bq[16 * h + n1] : a[16 * h + n1];
+                            const cpx v = z[16 * h + n1];
                             s2 = s2 + v;
                             sq2 = pfma(v, v, sq2);
                             mx = max3f(mx, v.x, v.y);
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                             const int c = 2 * (lane + 64 * h);
                             const bool in0 = (c >= lo_r) && (c < hi_r);
                             const bool in1 = (c >= lo_r - 1) && (c < hi_r - 1);
-                            const cpx v = s ? bq[16 * h + n1] : a[16 * h + n1];
+                            const cpx v = z[16 * h + n1];
                             const float y0 = in0 ? v.x : 0.0f, y1 = in1 ? v.y : 0.0f;
                             sm = (sm + y0) + y1;
                             sq = fmaf(y0, y0, fmaf(y1, y1, sq));
@@ -258,6 +261,10 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                     X.td[w][3][s] = SQ;
                 }
             }
+        };
+        if constexpr (FEAT & 2) {
+            if (s == 0) td_sums(a);
+            else td_sums(bq);
         }
         // one lane of wave 0 per window: both partials, the end points, the eight values
         auto td_finalize = [&]() {
