@@ -1,12 +1,13 @@
 """Turn gpurun_out/prof25 (tools/profile_fused25.sh) into profiles/rNN_*25000* summaries.
 usage: python tools/make_profiles25.py <round-number> [samples = 25000] [traces = 1048576]
-(4096: the one-wave-per-trace kernel k_wave, gpurun_out/prof4096 -> profiles/rNN_*4096*)"""
+(4096: the one-wave-per-trace kernel k_wave, gpurun_out/prof4096 -> profiles/rNN_*4096*; 8192: k_wave2)"""
 import csv, glob, json, sys, collections
 rnd = int(sys.argv[1]); tag = f"r{rnd:02d}"
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 25000
 TRACES = int(sys.argv[3]) if len(sys.argv) > 3 else 1048576
 P = "gpurun_out/prof25" if NS == 25000 else f"gpurun_out/prof{NS}"; OUT = "profiles"
-KERNEL = {25000: "k_fused25", 4096: "k_wave"}.get(NS, "k_fused25")
+KERNEL = {25000: "k_fused25", 4096: "k_wave<", 8192: "k_wave2<"}.get(NS, "k_fused25")
+KNAME = KERNEL.rstrip("<")
 ALG = NS * 4 + 16
 
 
@@ -38,7 +39,7 @@ if fetch is not None and write is not None:
     hbm = fetch * 1024.0 * corr + write * 1024.0
     json.dump({"round": rnd, "workload": f"config1_n{NS}",
                "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --samples {NS} --traces {TRACES} --config 1 --steps 2 --warmup 1 --no-cpu-baseline",
-               "kernel": f"{KERNEL} (every launch of the pass averaged)", "engine": "fused", "traces_per_launch": TRACES,
+               "kernel": f"{KNAME} (every launch of the pass averaged)", "engine": "fused", "traces_per_launch": TRACES,
                "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "fetch_correction": corr,
                "correction": f"factor of {OUT}/{tag}_traffic.json (load-only build of k_fused, the same 8 B / lane buffer loads)",
                "hbm_bytes_per_launch": hbm, "hbm_bytes_per_trace": hbm / TRACES, "algorithmic_bytes_per_trace": ALG},
@@ -51,7 +52,7 @@ for d in ("sq_1", "sq_2"):
         for n in names:
             v, k = counter(d, n)
             sq[n] = v / TRACES
-json.dump({"round": rnd, "kernel": f"{KERNEL}<0>" if NS == 4096 else "k_fused25<0,false>", "workload": f"config1_n{NS}", "traces_per_launch": TRACES, "per_trace": sq,
+json.dump({"round": rnd, "kernel": f"{KNAME}<0>" if NS in (4096, 8192) else "k_fused25<0,false>", "workload": f"config1_n{NS}", "traces_per_launch": TRACES, "per_trace": sq,
            "units": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES in units of 4 cycles, summed over the waves of a trace; SQ_INSTS_* wave-instructions"},
           open(f"{OUT}/{tag}_sq_counters_{NS}.json", "w"), indent=1)
 print(json.dumps(sq, indent=1))
