@@ -1,7 +1,7 @@
-// ofx_wave2.hip -- FUSED engine at 8192 samples: TWO WAVES PER TRACE.
+// ofx_wave2.hip -- FUSED engine at 8192 and 16384 samples: TWO / FOUR WAVES PER TRACE.
 //
 // Path: FeatureExtractors.of1x1_nodelay / _unconstrained / _constrained + baseline / integral /
-// maximum / minimum / psd_amp on 8192-sample traces (detprocess/core/algorithms.py:277-570, 650-885,
+// maximum / minimum / psd_amp on 8192- and 16384-sample traces (detprocess/core/algorithms.py:277-570, 650-885,
 // 952-1044; processing_data.py:712-772), as ofx_wave.hip does at 4096 samples.
 //
 // The packed transform has M' = 4096 complex points; it is split once, decimation in frequency, into two
@@ -25,7 +25,13 @@
 // flight.  The next trace is requested into the 128 registers of the two raw halves as soon as the lags
 // have been reduced / dumped.
 //
-// Roofline: HBM, 8192 x 4 + 16 B algorithmic per trace.
+// W = 4 (16384 samples, four waves per trace): the same with a radix-4 split,
+//   y_s[m] = (sum_j z[m + 2048 j] (-i)^{s j}) w_8192^{m s},   X[4 q + s] = FFT_2048(y_s)[q],
+// two quarters requested under the tail, two at the top of a trace.  The partners of the bins 4 q + 1 are
+// the bins 4 (2047 - q) + 3: the waves 1 and 3 swap the partner halves of their lanes through LDS before
+// and after the middle step (lane to lane, two more barriers); the waves 0 and 2 pair inside themselves.
+//
+// Roofline: HBM, N x 4 + 16 B algorithmic per trace.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,81 +47,119 @@ using namespace ofxfft;
 
 namespace {
 
-constexpr int VN = 8192;            // samples
-constexpr int VM = 4096;            // packed complex points = 2 x WM
-constexpr int VBLK = 128;           // two waves: one trace per workgroup
-constexpr int VWG_PER_CU = 4;
+// W waves per trace: N = 4096 W samples, W x 2048 packed complex points, one trace per workgroup of W waves,
+// eight waves per CU
 
 #ifndef OFX_WMID_DEPTH
 #define OFX_WMID_DEPTH 4            // (8 in k_wave: here the two raw halves of the next trace need the registers)
 #endif
 #include "ofx_wave_parts.h"
 
-struct Wave2X {                     // what the two waves of a trace tell each other (double-buffered by parity)
-    float chi[2];
+template <int W>
+struct Wave2X {                     // what the waves of a trace tell each other (double-buffered by parity)
+    float chi[W];
     float lag0;
-    OfxCand cand[2];
-    float td[OFX_MAX_TDWIN][4][2];
-    float lowp[OFX_MAX_SEARCHES][2];
-    float band[OFX_MAX_BANDS][2];
+    OfxCand cand[W];
+    float td[OFX_MAX_TDWIN][4][W];
+    float lowp[OFX_MAX_SEARCHES][W];
+    float band[OFX_MAX_BANDS][W];
 };
+template <int W>
 struct Wave2Shared {
-    WaveLds w[2];
-    Wave2X x[2];
+    WaveLds w[W];
+    Wave2X<W> x[2];
 };
-static_assert(sizeof(Wave2Shared) * VWG_PER_CU <= 160 * 1024, "LDS budget");
+static_assert(sizeof(Wave2Shared<2>) * 4 <= 160 * 1024, "LDS budget");
+static_assert(sizeof(Wave2Shared<4>) * 2 <= 160 * 1024, "LDS budget");
 constexpr int LDS_WAVE_FLOATS = sizeof(WaveLds) / 4;      // from w[0].xb to w[1].xb, in floats
 
 struct Wave2Tabs {
     const float2* t1;     // [6][64]     w_2048^{a n'}, a = 1, 2, 3, 4, 8, 12: the stage-1 anchors
     const float2* t2;     // [8][16]     w_128^{n3 k2}: seven per lane, kept in registers
-    const float2* ua;     // [64]        w_4096^{n}: the split twiddle (x w_64 for n' >= 64, x w_32^{n1} per row)
-    const float2* tbase;  // [2][64]     T(v, s) = i exp(-2 pi i (2 v + s) / N); slot j: T w_32^j
-    const float4* midW;   // [2][16][64] (W_k / 2, conj(W_p) / 2), k = 2 (v + 128 j) + s
-    const float2* midG;   // [2][16][64] (g_k', g_p')
-    float2 tb0hi;         // even wave, lane 0, slots j >= 8 (block 64)
+    const float2* ua;     // [W][2][64]  w_M'^{(n + 64 h) s}: the split twiddle of wave s (x a 64th root per row n1)
+    const float2* tbase;  // [W][64]     T(v, s) = i exp(-2 pi i (W v + s) / N); slot j: T w_32^j
+    const float4* midW;   // [W][16][64] (W_k / 2, conj(W_p) / 2), k = W (v + 128 j) + s
+    const float2* midG;   // [W][16][64] (g_k', g_p')
+    float2 tb0hi;         // wave 0, lane 0, slots j >= 8 (block 64)
     float2 wq;            // W_{M'/2}
     float gq;             // g_{M'/2}
 };
 
-constexpr float kC64 = 0.99518472667219688624f;     // cos(2 pi / 64)
-constexpr float kS64 = 0.09801714032956060199f;     // sin(2 pi / 64)
+// cos(2 pi j / 64), j = 0 .. 16
+constexpr double kCos64[17] = {
+    1.00000000000000000000, 0.99518472667219692873, 0.98078528040323043058, 0.95694033573220882438,
+    0.92387953251128673848, 0.88192126434835504956, 0.83146961230254523567, 0.77301045336273699338,
+    0.70710678118654757274, 0.63439328416364548779, 0.55557023301960228867, 0.47139673682599780857,
+    0.38268343236508983729, 0.29028467725446233105, 0.19509032201612833135, 0.09801714032956077016,
+    0.0};
+__host__ __device__ constexpr double cos64(int j) {
+    j = ((j % 64) + 64) % 64;
+    if (j <= 16) return kCos64[j];
+    if (j <= 32) return -kCos64[32 - j];
+    if (j <= 48) return -kCos64[j - 32];
+    return kCos64[64 - j];
+}
+__host__ __device__ constexpr double sin64(int j) { return cos64(j - 16); }
+// b * exp(DIR * 2 pi i NUM / 64), NUM a compile-time constant
+template <int NUM, int DIR>
+__device__ __forceinline__ cpx rot64(cpx b) {
+    constexpr int n = ((NUM % 64) + 64) % 64;
+    if constexpr (n % 2 == 0) {
+        return twmul<n / 2, DIR>(b);
+    } else {
+        constexpr float c = (float)cos64(n);
+        constexpr float s = (float)(DIR * sin64(n));
+        return pfma(swp(b), mk(-s, s), b * mk(c, c));
+    }
+}
 
-// the split twiddle of the odd wave, forward (INV = false: x w_4096^m) and back (x conj)
-template <int N1, bool INV>
+// the split twiddle of wave s, forward (INV = false: x w_M'^{m s}) and back (x conj): per element the lane's
+// anchor u_h = w_M'^{(lane + 64 h) s} and the row's constant w_M'^{128 n1 s} = exp(-2 pi i n1 S4 / 64), S4 = 4 s / W
+template <int S4, int N1, bool INV>
 __device__ __forceinline__ void split_tw(cpx (&d)[WNV], cpx u0, cpx u1) {
     if constexpr (N1 < 16) {
         if constexpr (!INV) {
-            d[N1] = twmul<N1, -1>(cmul(d[N1], u0));
-            d[16 + N1] = twmul<N1, -1>(cmul(d[16 + N1], u1));
+            d[N1] = rot64<N1 * S4, -1>(cmul(d[N1], u0));
+            d[16 + N1] = rot64<N1 * S4, -1>(cmul(d[16 + N1], u1));
         } else {
-            d[N1] = twmul<N1, +1>(cmulc(d[N1], u0));
-            d[16 + N1] = twmul<N1, +1>(cmulc(d[16 + N1], u1));
+            d[N1] = rot64<N1 * S4, +1>(cmulc(d[N1], u0));
+            d[16 + N1] = rot64<N1 * S4, +1>(cmulc(d[16 + N1], u1));
         }
-        split_tw<N1 + 1, INV>(d, u0, u1);
+        split_tw<S4, N1 + 1, INV>(d, u0, u1);
+    }
+}
+template <int W, bool INV>
+__device__ __forceinline__ void split_tw_of(int s, cpx (&d)[WNV], cpx u0, cpx u1) {
+    if (s == 1) split_tw<4 / W, 0, INV>(d, u0, u1);
+    if constexpr (W == 4) {
+        if (s == 2) split_tw<2, 0, INV>(d, u0, u1);
+        if (s == 3) split_tw<3, 0, INV>(d, u0, u1);
     }
 }
 
 // ------------------------------------------------------------------ the kernel
 // FEAT bit 0: a windowed / interpolating search (the lags are dumped to LDS); bit 1: time-domain
 // windows; bit 2: channel algebra on load.
-template <int FEAT>
-__global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd, Wave2Tabs tabs,
-                                                   const float* __restrict__ traces,
-                                                   const uint8_t* __restrict__ valid, long long n_traces,
-                                                   float* __restrict__ out) {
+template <int W, int FEAT>
+__global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd, Wave2Tabs tabs,
+                                                     const float* __restrict__ traces,
+                                                     const uint8_t* __restrict__ valid, long long n_traces,
+                                                     float* __restrict__ out) {
+    constexpr int VN = 4096 * W;        // samples
+    constexpr int VBLK = 64 * W;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    Wave2Shared& SH = *reinterpret_cast<Wave2Shared*>(smem_raw);
+    Wave2Shared<W>& SH = *reinterpret_cast<Wave2Shared<W>*>(smem_raw);
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
-    const int s = __builtin_amdgcn_readfirstlane(tid >> 6);       // parity of this wave's bins / its half of the lags
+    const int s = __builtin_amdgcn_readfirstlane(tid >> 6);       // residue of this wave's bins mod W / its part of the lags
     WaveLds& L = SH.w[s];
-    WaveLds& LO = SH.w[s ^ 1];
+    WaveLds& LO = SH.w[(W - s) % W == s ? s ^ 1 : (W - s) % W];   // W = 2: the other wave; W = 4: the partner of a crossing wave
+    const bool crossing = (W == 4) && (s & 1);                    // bins W q + s pair with W (2047 - q) + (W - s)
     const int pre = pd.pre;
     const __amdgpu_buffer_rsrc_t rw = make_rsrc(tabs.midW + s * 16 * 64, 16 * 64 * 16);
     const __amdgpu_buffer_rsrc_t rg = make_rsrc(tabs.midG + s * 16 * 64, 16 * 64 * 8);
-    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, 2 * WLOW * 8);
-    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, 2 * WLOW * 4);
+    const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(sd.s, W * WLOW * 8);
+    const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(sd.g, W * WLOW * 4);
     const size_t ev_stride = (size_t)pd.n_channels * VN;
     cpx* const xc = L.xb;
     const float* const xf0 = reinterpret_cast<const float*>(SH.w[0].xb);      // the dump: lag n at
@@ -135,12 +179,13 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
 #pragma unroll
         for (int k2 = 1; k2 < 8; ++k2) t2r[k2 - 1] = buf_ld2(rt2, n3 * 8, k2 * 128);
     }
-    cpx tb, u0;
+    cpx tb, u0, u1;
     {
-        const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, 128 * 8);
+        const __amdgpu_buffer_rsrc_t rtb = make_rsrc(tabs.tbase, W * 64 * 8);
         tb = buf_ld2(rtb, lane * 8, s * 512);
-        const __amdgpu_buffer_rsrc_t rua = make_rsrc(tabs.ua, 64 * 8);
-        u0 = buf_ld2(rua, lane * 8, 0);
+        const __amdgpu_buffer_rsrc_t rua = make_rsrc(tabs.ua, W * 128 * 8);
+        u0 = buf_ld2(rua, lane * 8, s * 1024);
+        u1 = buf_ld2(rua, lane * 8, s * 1024 + 512);
     }
     const cpx tbh = (s == 0 && lane == 0) ? mk(tabs.tb0hi.x, tabs.tb0hi.y) : tb;
     bool any_full = false;
@@ -148,18 +193,51 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
         const OfxSearchDev& sq = sd.search[q];
         any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 && sq.hi == VN;
     }
-    cpx a[WNV], bq[WNV];            // the raw halves z[m], z[m + 2048], m = 128 n1 + lane + 64 h
+    // the raw parts of the trace, m = 128 n1 + lane + 64 h:  W = 2: a = z[m], bq = z[m + 2048];
+    // W = 4: a = z[m], bq = z[m + 4096] requested under the tail, then bq = z[m + 2048], cq = z[m + 6144]
+    cpx a[WNV], bq[WNV];
     cpx d[WNV];
-    auto request = [&](long long bb) {
-        const float* e = traces + (size_t)bb * ev_stride;
-        const __amdgpu_buffer_rsrc_t rz = make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0), VN * 4);
+    auto load_part = [&](cpx (&z)[WNV], const float* chan, int part) {
+        const __amdgpu_buffer_rsrc_t rz = make_rsrc(chan, VN * 4);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int n1 = 0; n1 < 16; ++n1) {
-                a[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
-                bq[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + 16384);
-            }
+            for (int n1 = 0; n1 < 16; ++n1) z[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + part * 16384);
+    };
+    auto request = [&](long long bb) {
+        const float* e = traces + (size_t)bb * ev_stride + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0);
+        if constexpr (W == 2) {
+            const __amdgpu_buffer_rsrc_t rz = make_rsrc(e, VN * 4);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    a[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
+                    bq[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + 16384);
+                }
+        } else {
+            load_part(a, e, 0);
+            load_part(bq, e, 2);
+        }
+    };
+    // channel algebra on one part (FEAT bit 2): weight of the first term, then the other terms
+    [[maybe_unused]] auto combine_part = [&](cpx (&z)[WNV], long long bb, int part) {
+        if (pd.n_terms == 1 && pd.weight[0] == 1.0f) return;
+        const float* e = traces + (size_t)bb * ev_stride;
+        const float w0 = pd.weight[0];
+#pragma unroll
+        for (int j = 0; j < WNV; ++j) z[j] = z[j] * mk(w0, w0);
+        for (int c = 1; c < pd.n_terms; ++c) {
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(e + (size_t)pd.chan[c] * VN, VN * 4);
+            const float wgt = pd.weight[c];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const cpx zz = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024 + part * 16384);
+                    z[16 * h + n1] = pfma(mk(wgt, wgt), zz, z[16 * h + n1]);
+                }
+        }
     };
     long long b = (long long)blockIdx.x;
     bool have = b < n_traces;
@@ -187,41 +265,34 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
             continue;
         }
         par ^= 1;
-        Wave2X& X = SH.x[par];
+        Wave2X<W>& X = SH.x[par];
         // ------------------------------------------------ channel algebra
         if constexpr (FEAT & 4) {
-            if (!(pd.n_terms == 1 && pd.weight[0] == 1.0f)) {
-                const float* e = traces + (size_t)bcur * ev_stride;
-                const float w0 = pd.weight[0];
-#pragma unroll
-                for (int j = 0; j < WNV; ++j) {
-                    a[j] = a[j] * mk(w0, w0);
-                    bq[j] = bq[j] * mk(w0, w0);
-                }
-                for (int c = 1; c < pd.n_terms; ++c) {
-                    const __amdgpu_buffer_rsrc_t rc = make_rsrc(e + (size_t)pd.chan[c] * VN, VN * 4);
-                    const float wgt = pd.weight[c];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int n1 = 0; n1 < 16; ++n1) {
-                            const cpx za = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024);
-                            const cpx zb = buf_ld2(rc, (lane + 64 * h) * 8, n1 * 1024 + 16384);
-                            a[16 * h + n1] = pfma(mk(wgt, wgt), za, a[16 * h + n1]);
-                            bq[16 * h + n1] = pfma(mk(wgt, wgt), zb, bq[16 * h + n1]);
-                        }
-                }
-            }
+            combine_part(a, bcur, 0);
+            combine_part(bq, bcur, W == 2 ? 1 : 2);
         }
         // ------------------------------------------------ time-domain windows
-        // wave s sums over its half of the samples: index 4096 s + 256 n1 + 2 (lane + 64 h) + {0, 1}, rows
+        // wave s sums over its part of the samples: index 4096 s + 256 n1 + 2 (lane + 64 h) + {0, 1}, rows
         // 16 s + n1 of the host's classification; the partial sums meet in X.td
         [[maybe_unused]] auto td_sums = [&](const cpx (&z)[WNV]) {
             for (int w = 0; w < pd.n_tdwin; ++w) {
                 const int lo = pd.tdw[w].lo - 4096 * s, hi = pd.tdw[w].hi - 4096 * s;
                 float sm = 0.0f, sq = 0.0f, mx = -INFINITY, mn = INFINITY;
                 cpx s2 = mk(0.0f, 0.0f), sq2 = mk(0.0f, 0.0f);
-                const unsigned fullm = pd.tdw[w].full >> (16 * s), anym = fullm | (pd.tdw[w].edge >> (16 * s));
+                // rows of this part: 32 rows classified by the host (W = 2); 64 rows, classified here (W = 4)
+                unsigned fullm, anym;
+                if constexpr (W == 2) {
+                    fullm = pd.tdw[w].full >> (16 * s);
+                    anym = fullm | (pd.tdw[w].edge >> (16 * s));
+                } else {
+                    fullm = anym = 0;
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const int r0 = WROWS * n1;
+                        if (r0 < hi && r0 + WROWS > lo) anym |= 1u << n1;
+                        if (lo <= r0 && r0 + WROWS <= hi) fullm |= 1u << n1;
+                    }
+                }
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) {
                     if (!((anym >> n1) & 1u)) continue;                   // uniform: outside
@@ -263,10 +334,15 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
             }
         };
         if constexpr (FEAT & 2) {
-            if (s == 0) td_sums(a);
-            else td_sums(bq);
+            if constexpr (W == 2) {
+                if (s == 0) td_sums(a);
+                else td_sums(bq);
+            } else {
+                if (s == 0) td_sums(a);
+                if (s == 2) td_sums(bq);
+            }
         }
-        // one lane of wave 0 per window: both partials, the end points, the eight values
+        // one lane of wave 0 per window: the partials, the end points, the eight values
         auto td_finalize = [&]() {
             if constexpr (FEAT & 2) {
                 if (s == 0 && lane < pd.n_tdwin) {
@@ -284,39 +360,94 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                         first = e[lo];
                         last = e[hi - 1];
                     }
-                    const float S = X.td[w][0][0] + X.td[w][0][1];
+                    float S = 0.0f, SQ = 0.0f, MX = -INFINITY, MN = INFINITY;
+#pragma unroll
+                    for (int t = 0; t < W; ++t) {
+                        S += X.td[w][0][t];
+                        MX = fmaxf(MX, X.td[w][1][t]);
+                        MN = fminf(MN, X.td[w][2][t]);
+                        SQ += X.td[w][3][t];
+                    }
                     float* o = row + pd.tdw[w].out_off;
                     o[OFX_TD_BASELINE] = S / (float)(hi - lo);
                     o[OFX_TD_INTEGRAL] = (S - 0.5f * (first + last)) * pd.inv_fs;
-                    o[OFX_TD_MAXIMUM] = fmaxf(X.td[w][1][0], X.td[w][1][1]);
-                    o[OFX_TD_MINIMUM] = fminf(X.td[w][2][0], X.td[w][2][1]);
+                    o[OFX_TD_MAXIMUM] = MX;
+                    o[OFX_TD_MINIMUM] = MN;
                     o[OFX_TD_SUM] = S;
-                    o[OFX_TD_SUMSQ] = X.td[w][3][0] + X.td[w][3][1];
+                    o[OFX_TD_SUMSQ] = SQ;
                     o[OFX_TD_FIRST] = first;
                     o[OFX_TD_LAST] = last;
                 }
             }
         };
-        if (sd.n_search == 0) {                         // windows only
-            __syncthreads();
-            td_finalize();
-            if (have_next) {
-                if (valid) vnext = valid[bnext];
-                request(bnext);
-            }
-            vcur = vnext;
-            continue;
-        }
         // ---------------------------------------------------------------- the split: y_s
-        if (s == 0) {
+        if constexpr (W == 2) {
+            if (sd.n_search == 0) {                     // windows only
+                __syncthreads();
+                td_finalize();
+                if (have_next) {
+                    if (valid) vnext = valid[bnext];
+                    request(bnext);
+                }
+                vcur = vnext;
+                continue;
+            }
+            if (s == 0) {
 #pragma unroll
-            for (int j = 0; j < WNV; ++j) d[j] = a[j] + bq[j];
+                for (int j = 0; j < WNV; ++j) d[j] = a[j] + bq[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < WNV; ++j) d[j] = a[j] - bq[j];
+            }
         } else {
+            // z0 +- z2 in place, then the quarters 1 and 3 into bq and cq
+            const float sg = (s & 1) ? -1.0f : 1.0f;
 #pragma unroll
-            for (int j = 0; j < WNV; ++j) d[j] = a[j] - bq[j];
-            cpx uu = u0;
-            asm volatile("" : "+v"(uu));                // (no hoisting of the 32 row twiddles out of the loop)
-            split_tw<0, false>(d, uu, cmul(uu, mk(kC64, -kS64)));
+            for (int j = 0; j < WNV; ++j) a[j] = pfma(bq[j], mk(sg, sg), a[j]);
+            cpx cq[WNV];
+            {
+                const float* e = traces + (size_t)bcur * ev_stride + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0);
+                load_part(bq, e, 1);
+                load_part(cq, e, 3);
+            }
+            if constexpr (FEAT & 4) {
+                combine_part(bq, bcur, 1);
+                combine_part(cq, bcur, 3);
+            }
+            if constexpr (FEAT & 2) {
+                if (s == 1) td_sums(bq);
+                if (s == 3) td_sums(cq);
+            }
+            if (sd.n_search == 0) {                     // windows only
+                __syncthreads();
+                td_finalize();
+                if (have_next) {
+                    if (valid) vnext = valid[bnext];
+                    request(bnext);
+                }
+                vcur = vnext;
+                continue;
+            }
+            // y_s before its twiddle: (z0 +- z2) + rot (z1 +- z3), rot = 1, -i, -1, +i for s = 0 .. 3
+            const float sr = (s & 2) ? -1.0f : 1.0f;
+            if (s & 1) {
+#pragma unroll
+                for (int j = 0; j < WNV; ++j) {
+                    const cpx t = pfma(cq[j], mk(sg, sg), bq[j]);
+                    d[j] = pfma(swp(t), mk(sr, -sr), a[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WNV; ++j) {
+                    const cpx t = pfma(cq[j], mk(sg, sg), bq[j]);
+                    d[j] = pfma(t, mk(sr, sr), a[j]);
+                }
+            }
+        }
+        if (s != 0) {
+            cpx uu0 = u0, uu1 = u1;
+            asm volatile("" : "+v"(uu0), "+v"(uu1));    // (no hoisting of the 32 element twiddles out of the loop)
+            split_tw_of<W, false>(s, d, uu0, uu1);
         }
         // ---------------------------------------------------------------- F1
         dft<16, -1, WNV, 0>(d);
@@ -363,6 +494,19 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
         // ------------------------------------------- F3, middle, I3 (registers)
         dft<16, -1, WNV, 0>(d);
         dft<16, -1, WNV, 16>(d);
+        // W = 4, waves 1 and 3: the partner halves of the lanes change hands (bins 4 q + 1 pair with
+        // 4 (2047 - q) + 3): lane to lane, row stride 17, first half of the exchange buffer
+        if constexpr (W == 4) {
+            if (crossing) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xc[lane * WLD2 + j] = d[16 + j];
+            }
+            __syncthreads();
+            if (crossing) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) d[16 + j] = LO.xb[lane * WLD2 + j];
+            }
+        }
         cpx chi2v = mk(0.0f, 0.0f);
         {
             int lm = lane;
@@ -389,9 +533,23 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                     for (int j = 9; j < 32; ++j) d[j] = L.perm[wperm_out_src(j)];
                     d[8] = zq + zq;
                 }
-            } else {
+            } else if (!crossing) {
                 wmid<0, 1>(d, rw, rg, lm, L, tlo, thi, mtw, mtg, chi2v);
+            } else {
+                wmid<0, 2>(d, rw, rg, lm, L, tlo, thi, mtw, mtg, chi2v, &LO);
             }
+        }
+        if constexpr (W == 4) {                         // ... and back (second half of the buffer)
+            if (crossing) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xc[(64 + lane) * WLD2 + j] = d[16 + j];
+            }
+            __syncthreads();
+            if (crossing) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) d[16 + j] = LO.xb[(64 + lane) * WLD2 + j];
+            }
+            __syncthreads();                            // the buffers are the waves' own again
         }
         dft<16, +1, WNV, 0>(d);
         dft<16, +1, WNV, 16>(d);
@@ -434,19 +592,19 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
         dft<16, +1, WNV, 0>(d);
         dft<16, +1, WNV, 16>(d);
         // d[16 h + n1] = y'_s[m], m = 128 n1 + lane + 64 h
-        // ---------------------------------------------------------------- the two halves meet
-        if (s == 1) {
-            cpx uu = u0;
-            asm volatile("" : "+v"(uu));
-            split_tw<0, true>(d, uu, cmul(uu, mk(kC64, -kS64)));
+        // ---------------------------------------------------------------- the parts meet
+        if (s != 0) {
+            cpx uu0 = u0, uu1 = u1;
+            asm volatile("" : "+v"(uu0), "+v"(uu1));
+            split_tw_of<W, true>(s, d, uu0, uu1);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = d[16 * h + n1];
         if (lane == 0) X.chi[s] = chi_w;
-        __syncthreads();                                // B1: both y' are in LDS
-        {
+        __syncthreads();                                // B1: every u_t = conj(w^{m t}) y'_t is in LDS
+        if constexpr (W == 2) {
             const cpx* const xo = LO.xb;
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -454,6 +612,24 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                 for (int n1 = 0; n1 < 16; ++n1) {
                     const cpx o = xo[128 * n1 + lane + 64 * h];
                     d[16 * h + n1] = s ? o - d[16 * h + n1] : d[16 * h + n1] + o;
+                }
+        } else {
+            // part s of the lags: sum_t u_t i^{t s}
+            const cpx* const x0 = SH.w[0].xb;
+            const cpx* const x1 = SH.w[1].xb;
+            const cpx* const x2 = SH.w[2].xb;
+            const cpx* const x3 = SH.w[3].xb;
+            const float sg = (s & 1) ? -1.0f : 1.0f;    // i^{2 s}
+            const float sr = (s & 2) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int n1 = 0; n1 < 16; ++n1) {
+                    const int m = 128 * n1 + lane + 64 * h;
+                    const cpx e02 = pfma(x2[m], mk(sg, sg), x0[m]);        // u0 + i^{2s} u2
+                    const cpx e13 = pfma(x3[m], mk(sg, sg), x1[m]);        // u1 + i^{2s} u3 (times i^s below)
+                    // i^s = 1, i, -1, -i:  s odd -> (-y, x) sr ; s even -> sr
+                    d[16 * h + n1] = (s & 1) ? pfma(swp(e13), mk(-sr, sr), e02) : pfma(e13, mk(sr, sr), e02);
                 }
         }
         // d[16 h + n1] = (A(n), A(n + 1)), lag n = 4096 s + 256 n1 + 2 (lane + 64 h)
@@ -465,9 +641,9 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
         cpx lk_s[NLK];
         float lk_g[NLK];
 #pragma unroll
-        for (int i = 0; i < NLK; ++i) {                 // this wave's low bins: k = 2 (lane + 64 i) + s
-            lk_s[i] = buf_ld2(rs_s, (2 * (lt + 64 * i) + s) * 8, 0);
-            lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, (2 * (lt + 64 * i) + s) * 4, 0, 0));
+        for (int i = 0; i < NLK; ++i) {                 // this wave's low bins: k = W (lane + 64 i) + s
+            lk_s[i] = buf_ld2(rs_s, (W * (lt + 64 * i) + s) * 8, 0);
+            lk_g[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_g, (W * (lt + 64 * i) + s) * 4, 0, 0));
         }
         OfxCand mybest = ofx_cand_none();
         if (s == 0 && lane == 0) X.lag0 = d[0].x;
@@ -531,8 +707,8 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                 const int lo = pd.band[i].k_lo, hi = pd.band[i].k_hi;
                 float acc = 0.0f;
                 for (int k = lo + lt; k < hi; k += 64) {
-                    if ((k & 1) == s) {
-                        const cpx x2 = L.xlow[k >> 1];
+                    if ((k & (W - 1)) == s) {
+                        const cpx x2 = L.xlow[k / W];
                         acc += sqrtf(2.0f * cpsd * fmaf(x2.x, x2.x, x2.y * x2.y));
                     }
                 }
@@ -541,17 +717,23 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
             }
         }
         __syncthreads();                                // B3: chi2_0, candidates, lag 0, window and band partials, dump
-        const float chi0 = X.chi[0] + X.chi[1];
+        float chi0 = X.chi[0];
         OfxCand fullbest = X.cand[0];
-        {
-            const OfxCand c1 = X.cand[1];
+#pragma unroll
+        for (int t = 1; t < W; ++t) {
+            chi0 += X.chi[t];
+            const OfxCand c1 = X.cand[t];
             if (ofx_cand_better(c1.key, c1.idx, fullbest)) fullbest = c1;
         }
         const float a_lag0 = X.lag0;
         td_finalize();
         if (s == 0 && lane == 0)
-            for (int i = 0; i < pd.n_bands; ++i)
-                row[pd.band[i].out_off] = (X.band[i][0] + X.band[i][1]) / (float)(pd.band[i].k_hi - pd.band[i].k_lo);
+            for (int i = 0; i < pd.n_bands; ++i) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int t = 0; t < W; ++t) acc += X.band[i][t];
+                row[pd.band[i].out_off] = acc / (float)(pd.band[i].k_hi - pd.band[i].k_lo);
+            }
 #pragma unroll 1
         for (int q = 0; q < sd.n_search; ++q) {
             const OfxSearchDev& sq = sd.search[q];
@@ -602,7 +784,7 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                                           chi0);
                 }
             }
-            // low-frequency chi2: this wave's bins k = 2 (lane + 64 i) + s, the phase along a chain
+            // low-frequency chi2: this wave's bins k = W (lane + 64 i) + s, the phase along a chain
             const int dl = best.idx - pre;
             auto phase_of = [&](int k) {
                 const int m = (int)(((unsigned)k * (unsigned)dl) & (unsigned)(VN - 1));
@@ -610,12 +792,12 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
                 sincospif(-2.0f * ((float)m + (float)k * ref.frac) / (float)VN, &sn, &cs);
                 return mk(cs, sn);
             };
-            cpx ph = phase_of(2 * lt + s);
-            const cpx step = phase_of(128);
+            cpx ph = phase_of(W * lt + s);
+            const cpx step = phase_of(64 * W);
             float low = 0.0f;
 #pragma unroll
             for (int i = 0; i < NLK; ++i) {
-                const int k = 2 * (lt + 64 * i) + s;
+                const int k = W * (lt + 64 * i) + s;
                 if (k < sq.nlow) {
                     const cpx x2 = L.xlow[lt + 64 * i];
                     const float pr = ph.x * lk_s[i].x - ph.y * lk_s[i].y;
@@ -629,9 +811,12 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
             low = ofx_wave_sum(low);
             if (lane == 0) X.lowp[q][s] = low;
             __syncthreads();                            // the two partial sums; the scans of the dump are done
-            if (s == 0 && lane == 0)
-                ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, X.lowp[q][0] + X.lowp[q][1],
-                                 refine ? &ref : nullptr);
+            if (s == 0 && lane == 0) {
+                float lw = 0.0f;
+#pragma unroll
+                for (int t = 0; t < W; ++t) lw += X.lowp[q][t];
+                ofx_write_search(row, sq, sd, pd.inv_fs, pre, chi0, best, lw, refine ? &ref : nullptr);
+            }
         }
         vcur = vnext;
     }
@@ -639,12 +824,14 @@ __global__ __launch_bounds__(VBLK, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev sd,
 
 }  // namespace
 
-bool ofx_wave2_supported(int n_samples) { return n_samples == VN; }
+bool ofx_wave2_supported(int n_samples) { return n_samples == 8192 || n_samples == 16384; }
 
+template <int W>
 static int wave2_tables(ofx_plan* p) {
     if (p->d_tw1) return OFX_OK;
+    constexpr int VN = 4096 * W, VM = 2048 * W;
     const double PI2 = 6.283185307179586476925286766559;
-    std::vector<float2> t1(6 * 64), t2(128 + 64 + 128);
+    std::vector<float2> t1(6 * 64), t2(128 + W * 128 + W * 64);
     const int anchor_mult[6] = {1, 2, 3, 4, 8, 12};
     for (int i = 0; i < 6; ++i)
         for (int n = 0; n < 64; ++n) {
@@ -656,73 +843,82 @@ static int wave2_tables(ofx_plan* p) {
             const double a = -PI2 * (double)((k2 * n3) % 128) / 128.0;
             t2[k2 * 16 + n3] = make_float2((float)std::cos(a), (float)std::sin(a));
         }
-    for (int n = 0; n < 64; ++n) {          // ua[n] = w_4096^n
-        const double a = -PI2 * (double)n / VM;
-        t2[128 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
-    }
-    for (int s = 0; s < 2; ++s)
-        for (int v = 0; v < 64; ++v) {      // tbase[s][v] = i exp(-2 pi i (2 v + s) / N)
-            const double a = -PI2 * (double)(2 * v + s) / VN;
-            t2[192 + 64 * s + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
+    for (int s = 0; s < W; ++s)
+        for (int n = 0; n < 128; ++n) {     // ua[s][h][lane] = w_M'^{(lane + 64 h) s}
+            const double a = -PI2 * (double)((n * s) % VM) / VM;
+            t2[128 + s * 128 + n] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+    for (int s = 0; s < W; ++s)
+        for (int v = 0; v < 64; ++v) {      // tbase[s][v] = i exp(-2 pi i (W v + s) / N)
+            const double a = -PI2 * (double)(W * v + s) / VN;
+            t2[128 + W * 128 + 64 * s + v] = make_float2((float)-std::sin(a), (float)std::cos(a));
         }
     return fused_upload_tables(p, t1, t2);
 }
 
-// Middle-step tables of one slot: per wave s the rows of ofx_wave.hip at the global bins k = 2 q + s,
-// q = v + 128 j (even wave, lane 0: 128 j for j < 8, 64 + 128 (j - 8) above), partner M' - k.
+// Middle-step tables of one slot: per wave s the rows of ofx_wave.hip at the global bins k = W q + s,
+// q = v + 128 j (wave 0, lane 0: 128 j for j < 8, 64 + 128 (j - 8) above), partner M' - k.
 //   d_pq (float4 units): [s][16][64] midW, then [s][16][64] midG as float2, last entry the self-paired bin.
-int ofx_wave2_prepare_slot(ofx_plan* p, int slot, const double* wf) {
-    int rc = wave2_tables(p);
+template <int W>
+static int wave2_prepare_slot(ofx_plan* p, int slot, const double* wf) {
+    int rc = wave2_tables<W>(p);
     if (rc) return rc;
-    constexpr int NW = 2 * 16 * 64, NG = NW / 2;
+    constexpr int VM = 2048 * W, NW = W * 16 * 64, NG = NW / 2;
     std::vector<float4> tab(NW + NG + 1, make_float4(0.f, 0.f, 0.f, 0.f));
     float2* tg = reinterpret_cast<float2*>(tab.data() + NW);
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < W; ++s)
         fused_fill_slot_tables(tab.data() + s * 16 * 64, tg + s * 16 * 64, wf, p->slot[slot].g_host, VM, 64, 64, 16,
                                [s](int v, int j) {
-                                   const int q = (s == 1 || v != 0) ? v + 128 * j
+                                   const int q = (s != 0 || v != 0) ? v + 128 * j
                                                                     : (j < 8 ? 128 * j : 64 + 128 * (j - 8));
-                                   return 2 * q + s;
+                                   return W * q + s;
                                });
     return fused_finish_slot_tables(p, slot, wf, tab, VM);
 }
+int ofx_wave2_prepare_slot(ofx_plan* p, int slot, const double* wf) {
+    return p->N == 8192 ? wave2_prepare_slot<2>(p, slot, wf) : wave2_prepare_slot<4>(p, slot, wf);
+}
 
-template <int FEAT>
+template <int W, int FEAT>
 static int launch_wave2(ofx_plan* p, const OfxPlanDev& pd, const OfxSlotDev& sd, const Wave2Tabs& tabs,
                         const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
                         hipStream_t st) {
-    OFX_LDS_ATTR_ONCE((k_wave2<FEAT>), sizeof(Wave2Shared));
-    long long grid = (long long)p->cu_count * VWG_PER_CU;
+    OFX_LDS_ATTR_ONCE((k_wave2<W, FEAT>), sizeof(Wave2Shared<W>));
+    long long grid = (long long)p->cu_count * (8 / W);
     if (grid > n) grid = n;
     size_t tix = 0;
     int rc = ofx_time_begin(p, st, &tix);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_wave2<FEAT>), dim3((unsigned)grid), dim3(VBLK), sizeof(Wave2Shared), st, pd, sd, tabs,
-                       d_traces, d_valid, n, d_out);
+    hipLaunchKernelGGL((k_wave2<W, FEAT>), dim3((unsigned)grid), dim3(64 * W), sizeof(Wave2Shared<W>), st, pd, sd,
+                       tabs, d_traces, d_valid, n, d_out);
     rc = ofx_time_end(p, st, tix);
     if (rc) return rc;
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
-int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
-                      hipStream_t st) {
-    int rc = wave2_tables(p);
+template <int W>
+static int wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                         hipStream_t st) {
+    constexpr int VN = 4096 * W;
+    int rc = wave2_tables<W>(p);
     if (rc) return rc;
     OfxPlanDev pd;
     ofx_fill_plan_dev(p, &pd);
-    struct G { enum { N = VN, ROWS = WROWS, NROWS = 32 }; };
-    fused_classify_windows<G>(pd);
+    if constexpr (W == 2) {
+        struct G { enum { N = 8192, ROWS = WROWS, NROWS = 32 }; };
+        fused_classify_windows<G>(pd);
+    }
     Wave2Tabs tabs;
     memset(&tabs, 0, sizeof(tabs));
     tabs.t1 = p->d_tw1;
     tabs.t2 = p->d_tw2;
     tabs.ua = p->d_tw2 + 128;
-    tabs.tbase = p->d_tw2 + 192;
+    tabs.tbase = p->d_tw2 + 128 + W * 128;
     {
-        // even wave, lane 0, slots j >= 8: bin 2 (64 + 128 (j - 8)) = 256 j + (128 - 2048):
-        // i exp(-2 pi i (128 - 2048) / N) = -exp(-2 pi i 128 / N)
-        const double a = -6.283185307179586476925286766559 * 128.0 / VN;
+        // wave 0, lane 0, slots j >= 8: bin W (64 + 128 (j - 8)) = 128 W j + W (64 - 1024):
+        // i exp(-2 pi i W (64 - 1024) / N) = -exp(-2 pi i 64 / 4096)
+        const double a = -6.283185307179586476925286766559 * 64.0 / 4096.0;
         tabs.tb0hi = make_float2((float)-std::cos(a), (float)-std::sin(a));
     }
     tabs.midW = reinterpret_cast<const float4*>(p->d_tw1);      // never read without searches
@@ -734,9 +930,9 @@ int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
         OfxSlotDev sd;
         ofx_fill_slot_dev(p, s, &sd);
         for (int q = 0; q < sd.n_search; ++q)
-            if (sd.search[q].nlow > 2 * WLOW) {
+            if (sd.search[q].nlow > W * WLOW) {
                 ofx_set_error("FUSED engine (%d samples): lowchi2_fcutoff covers %d bins (> %d)", VN,
-                              sd.search[q].nlow, 2 * WLOW);
+                              sd.search[q].nlow, W * WLOW);
                 return OFX_ERR_UNSUPPORTED;
             }
         slots[nslots++] = s;
@@ -748,9 +944,9 @@ int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             return OFX_ERR_UNSUPPORTED;
         }
         for (int i = 0; i < pd.n_bands; ++i)
-            if (pd.band[i].k_hi > 2 * WLOW) {
+            if (pd.band[i].k_hi > W * WLOW) {
                 ofx_set_error("FUSED engine (%d samples): band [%d,%d) exceeds the %d stashed bins", VN,
-                              pd.band[i].k_lo, pd.band[i].k_hi, 2 * WLOW);
+                              pd.band[i].k_lo, pd.band[i].k_hi, W * WLOW);
                 return OFX_ERR_UNSUPPORTED;
             }
     }
@@ -761,7 +957,7 @@ int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
             const int s = slots[li];
             ofx_fill_slot_dev(p, s, &sd);
             tabs.midW = p->slot[s].d_pq;
-            tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + 2 * 16 * 64);
+            tabs.midG = reinterpret_cast<const float2*>(p->slot[s].d_pq + W * 16 * 64);
             tabs.wq = make_float2(p->slot[s].wq_x, p->slot[s].wq_y);
             tabs.gq = p->slot[s].gq;
         }
@@ -775,12 +971,17 @@ int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid
         if (pd.n_tdwin > 0) feat |= 2;
         if (p->n_channels > 1 || p->n_terms > 1 || p->weight[0] != 1.0) feat |= 4;
         switch (feat) {
-#define OFX_CASE(F) case F: rc = launch_wave2<F>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st); break;
+#define OFX_CASE(F) case F: rc = launch_wave2<W, F>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st); break;
             OFX_CASE(0) OFX_CASE(1) OFX_CASE(2) OFX_CASE(3) OFX_CASE(4) OFX_CASE(5) OFX_CASE(6)
 #undef OFX_CASE
-            default: rc = launch_wave2<7>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
+            default: rc = launch_wave2<W, 7>(p, pd, sd, tabs, d_traces, d_valid, n, d_out, st);
         }
         if (rc) return rc;
     }
     return OFX_OK;
+}
+int ofx_wave2_process(ofx_plan* p, const float* d_traces, const uint8_t* d_valid, long long n, float* d_out,
+                      hipStream_t st) {
+    return p->N == 8192 ? wave2_process<2>(p, d_traces, d_valid, n, d_out, st)
+                        : wave2_process<4>(p, d_traces, d_valid, n, d_out, st);
 }

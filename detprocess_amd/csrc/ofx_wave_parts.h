@@ -87,10 +87,12 @@ __device__ __forceinline__ void wmid_request_first(float4 (&tw)[WMID], cpx (&tg)
 // ODD = 0: the wave holds the bins q = v + 128 j of a transform whose pairs are (q, M - q) -- k_wave, and the
 // even wave of k_wave2 --, lane 0 with the two self-paired blocks; ODD = 1: pairs (q, M - 1 - q) -- the odd wave of
 // k_wave2 (global bins 2 q + 1) --, no self-paired block.  The two differ in where the low bins land.
+// ODD = 2: a crossing wave of k_wave2 with four waves (its partners are another wave's bins): the partner side of
+// the low bins goes to that wave's stash, LP.
 template <int J, int ODD = 0>
 __device__ __forceinline__ void wmid(cpx (&d)[WNV], __amdgpu_buffer_rsrc_t rw, __amdgpu_buffer_rsrc_t rg,
                                      int v, WaveLds& L, cpx tlo, cpx thi, float4 (&tw)[WMID],
-                                     cpx (&tg)[WMID], cpx& chi) {
+                                     cpx (&tg)[WMID], cpx& chi, [[maybe_unused]] WaveLds* LP = nullptr) {
     if constexpr (J < 16) {
         const float4 w = tw[J % WMID];
         const cpx g = tg[J % WMID];
@@ -105,9 +107,11 @@ __device__ __forceinline__ void wmid(cpx (&d)[WNV], __amdgpu_buffer_rsrc_t rw, _
         if constexpr (ODD == 0) {
             if constexpr (J >= 14) L.xlow[v != 0 ? 128 * (16 - J) - v : WLOW + 1] = cconj(xp2);
             if constexpr (J == 8 || J == 9) L.xlow[v == 0 ? 64 + 128 * (J - 8) : WLOW + 2] = xk2;
-        } else {
+        } else if constexpr (ODD == 1) {
             if constexpr (J >= 14) L.xlow[128 * (16 - J) - 1 - v] = cconj(xp2);     // p = 127 - v + 128 (15 - J)
+        } else {
+            if constexpr (J >= 14) LP->xlow[128 * (16 - J) - 1 - v] = cconj(xp2);
         }
-        wmid<J + 1, ODD>(d, rw, rg, v, L, tlo, thi, tw, tg, chi);
+        wmid<J + 1, ODD>(d, rw, rg, v, L, tlo, thi, tw, tg, chi, LP);
     }
 }

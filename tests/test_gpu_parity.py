@@ -372,7 +372,7 @@ def test_argument_errors_surface_as_exceptions():
     with pytest.raises(ValueError):
         OFPlan(4, 1, FS)                               # too short
     with pytest.raises(_lib.OfxError):
-        OFPlan(16384, 100, FS, engine="fused")         # no register-resident kernel at this length
+        OFPlan(2048, 100, FS, engine="fused")          # no register-resident kernel at this length
     plan, ft, filt, tmpl, psd = _mk(4096, engine="rocfft")
     with pytest.raises(ValueError):
         plan.add_search(0, "delay", 100, 100)          # empty window

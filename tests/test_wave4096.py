@@ -14,7 +14,7 @@ FS = 1.25e6
 N = 4096
 
 
-@pytest.fixture(autouse=True, params=[4096, 8192])
+@pytest.fixture(autouse=True, params=[4096, 8192, 16384])
 def _trace_length(request):
     global N
     N = request.param
