@@ -27,7 +27,7 @@
 //
 // W = 4 (16384 samples, four waves per trace): the same with a radix-4 split,
 //   y_s[m] = (sum_j z[m + 2048 j] (-i)^{s j}) w_8192^{m s},   X[4 q + s] = FFT_2048(y_s)[q],
-// two quarters requested under the tail, two at the top of a trace.  The partners of the bins 4 q + 1 are
+// each wave loading its own quarter and the quarters meeting through LDS (the mirror image of the inverse side).  The partners of the bins 4 q + 1 are
 // the bins 4 (2047 - q) + 3: the waves 1 and 3 swap the partner halves of their lanes through LDS before
 // and after the middle step (lane to lane, two more barriers); the waves 0 and 2 pair inside themselves.
 //
@@ -193,9 +193,11 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
         const OfxSearchDev& sq = sd.search[q];
         any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 && sq.hi == VN;
     }
-    // the raw parts of the trace, m = 128 n1 + lane + 64 h:  W = 2: a = z[m], bq = z[m + 2048];
-    // W = 4: a = z[m], bq = z[m + 4096] requested under the tail, then bq = z[m + 2048], cq = z[m + 6144]
-    cpx a[WNV], bq[WNV];
+    // the raw parts of the trace, m = 128 n1 + lane + 64 h:  W = 2: a = z[m], bq = z[m + 2048], both in both
+    // waves (the second read of a line is an L2 hit); W = 4: a = z[m + 2048 s], the wave's own quarter -- the
+    // quarters meet through LDS (four readers per line were four HBM reads: 328 KB of traffic per 64 KB trace)
+    cpx a[WNV];
+    [[maybe_unused]] cpx bq[WNV];
     cpx d[WNV];
     auto load_part = [&](cpx (&z)[WNV], const float* chan, int part) {
         const __amdgpu_buffer_rsrc_t rz = make_rsrc(chan, VN * 4);
@@ -216,8 +218,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                     bq[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + 16384);
                 }
         } else {
-            load_part(a, e, 0);
-            load_part(bq, e, 2);
+            load_part(a, e, s);             // four waves: each loads its own quarter, once
         }
     };
     // channel algebra on one part (FEAT bit 2): weight of the first term, then the other terms
@@ -268,8 +269,12 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
         Wave2X<W>& X = SH.x[par];
         // ------------------------------------------------ channel algebra
         if constexpr (FEAT & 4) {
-            combine_part(a, bcur, 0);
-            combine_part(bq, bcur, W == 2 ? 1 : 2);
+            if constexpr (W == 2) {
+                combine_part(a, bcur, 0);
+                combine_part(bq, bcur, 1);
+            } else {
+                combine_part(a, bcur, s);
+            }
         }
         // ------------------------------------------------ time-domain windows
         // wave s sums over its part of the samples: index 4096 s + 256 n1 + 2 (lane + 64 h) + {0, 1}, rows
@@ -338,8 +343,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                 if (s == 0) td_sums(a);
                 else td_sums(bq);
             } else {
-                if (s == 0) td_sums(a);
-                if (s == 2) td_sums(bq);
+                td_sums(a);
             }
         }
         // one lane of wave 0 per window: the partials, the end points, the eight values
@@ -400,24 +404,6 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                 for (int j = 0; j < WNV; ++j) d[j] = a[j] - bq[j];
             }
         } else {
-            // z0 +- z2 in place, then the quarters 1 and 3 into bq and cq
-            const float sg = (s & 1) ? -1.0f : 1.0f;
-#pragma unroll
-            for (int j = 0; j < WNV; ++j) a[j] = pfma(bq[j], mk(sg, sg), a[j]);
-            cpx cq[WNV];
-            {
-                const float* e = traces + (size_t)bcur * ev_stride + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0);
-                load_part(bq, e, 1);
-                load_part(cq, e, 3);
-            }
-            if constexpr (FEAT & 4) {
-                combine_part(bq, bcur, 1);
-                combine_part(cq, bcur, 3);
-            }
-            if constexpr (FEAT & 2) {
-                if (s == 1) td_sums(bq);
-                if (s == 3) td_sums(cq);
-            }
             if (sd.n_search == 0) {                     // windows only
                 __syncthreads();
                 td_finalize();
@@ -428,21 +414,37 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                 vcur = vnext;
                 continue;
             }
-            // y_s before its twiddle: (z0 +- z2) + rot (z1 +- z3), rot = 1, -i, -1, +i for s = 0 .. 3
-            const float sr = (s & 2) ? -1.0f : 1.0f;
-            if (s & 1) {
+            // the quarters meet: y_s before its twiddle = sum_j z_j (-i)^{s j}, every wave at its own (lane, register)
 #pragma unroll
-                for (int j = 0; j < WNV; ++j) {
-                    const cpx t = pfma(cq[j], mk(sg, sg), bq[j]);
-                    d[j] = pfma(swp(t), mk(sr, -sr), a[j]);
-                }
-            } else {
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int j = 0; j < WNV; ++j) {
-                    const cpx t = pfma(cq[j], mk(sg, sg), bq[j]);
-                    d[j] = pfma(t, mk(sr, sr), a[j]);
-                }
+                for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = a[16 * h + n1];
+            __syncthreads();
+            {
+                const cpx* const x0 = SH.w[0].xb;
+                const cpx* const x1 = SH.w[1].xb;
+                const cpx* const x2 = SH.w[2].xb;
+                const cpx* const x3 = SH.w[3].xb;
+                const float sg = (s & 1) ? -1.0f : 1.0f;    // (-i)^{2 s}
+                const float sr = (s & 2) ? -1.0f : 1.0f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const int m = 128 * n1 + lane + 64 * h;
+                        const cpx e02 = pfma(x2[m], mk(sg, sg), x0[m]);
+                        const cpx e13 = pfma(x3[m], mk(sg, sg), x1[m]);
+                        // (-i)^s = 1, -i, -1, i:  s odd -> (y, -x) sr ; s even -> sr
+                        d[16 * h + n1] = (s & 1) ? pfma(swp(e13), mk(sr, -sr), e02) : pfma(e13, mk(sr, sr), e02);
+                        // (four reads per element: the fence ties the four results of a row group to their
+                        // place -- without it the compiler reads all 128 values first and combines them after
+                        // the barrier: 256 registers of LDS data, 150 of them spilled, in the first build)
+                        if ((n1 & 3) == 3)
+                            asm volatile("" : "+v"(d[16 * h + n1 - 3]), "+v"(d[16 * h + n1 - 2]), "+v"(d[16 * h + n1 - 1]),
+                                         "+v"(d[16 * h + n1]) :: "memory");
+                    }
             }
+            __syncthreads();                            // the buffers are the waves' own again
         }
         if (s != 0) {
             cpx uu0 = u0, uu1 = u1;
@@ -630,6 +632,9 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                     const cpx e13 = pfma(x3[m], mk(sg, sg), x1[m]);        // u1 + i^{2s} u3 (times i^s below)
                     // i^s = 1, i, -1, -i:  s odd -> (-y, x) sr ; s even -> sr
                     d[16 * h + n1] = (s & 1) ? pfma(swp(e13), mk(-sr, sr), e02) : pfma(e13, mk(sr, sr), e02);
+                    if ((n1 & 3) == 3)
+                        asm volatile("" : "+v"(d[16 * h + n1 - 3]), "+v"(d[16 * h + n1 - 2]), "+v"(d[16 * h + n1 - 1]),
+                                     "+v"(d[16 * h + n1]) :: "memory");
                 }
         }
         // d[16 h + n1] = (A(n), A(n + 1)), lag n = 4096 s + 256 n1 + 2 (lane + 64 h)

@@ -6,8 +6,8 @@ rnd = int(sys.argv[1]); tag = f"r{rnd:02d}"
 NS = int(sys.argv[2]) if len(sys.argv) > 2 else 25000
 TRACES = int(sys.argv[3]) if len(sys.argv) > 3 else 1048576
 P = "gpurun_out/prof25" if NS == 25000 else f"gpurun_out/prof{NS}"; OUT = "profiles"
-KERNEL = {25000: "k_fused25", 4096: "k_wave<", 8192: "k_wave2<"}.get(NS, "k_fused25")
-KNAME = KERNEL.rstrip("<")
+KERNEL = {25000: "k_fused25", 4096: "k_wave<", 8192: "k_wave2<2", 16384: "k_wave2<4"}.get(NS, "k_fused25")
+KNAME = KERNEL.split("<")[0]
 ALG = NS * 4 + 16
 
 
@@ -52,7 +52,7 @@ for d in ("sq_1", "sq_2"):
         for n in names:
             v, k = counter(d, n)
             sq[n] = v / TRACES
-json.dump({"round": rnd, "kernel": f"{KNAME}<0>" if NS in (4096, 8192) else "k_fused25<0,false>", "workload": f"config1_n{NS}", "traces_per_launch": TRACES, "per_trace": sq,
+json.dump({"round": rnd, "kernel": f"{KNAME}<0>" if NS in (4096, 8192, 16384) else "k_fused25<0,false>", "workload": f"config1_n{NS}", "traces_per_launch": TRACES, "per_trace": sq,
            "units": "SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES in units of 4 cycles, summed over the waves of a trace; SQ_INSTS_* wave-instructions"},
           open(f"{OUT}/{tag}_sq_counters_{NS}.json", "w"), indent=1)
 print(json.dumps(sq, indent=1))
