@@ -281,7 +281,7 @@ def run_fused(cases, seed, verbose=True, n=32768):
         for _ in range(int(rng.integers(0, 4))):
             lo = int(rng.integers(0, n - 2)); tdw.append((lo, int(rng.integers(lo + 1, n))))
         # beyond 512 bins: the stash (32768 samples); 25000 samples: up to the 1250 bins kept in LDS
-        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, {32768: 120000.0, 4096: 70000.0, 8192: 70000.0}.get(n, 62000.0)]))
+        fcut_c = float(rng.choice([10000.0, 10000.0, 50000.0, {32768: 120000.0, 4096: 70000.0, 8192: 70000.0, 16384: 70000.0}.get(n, 62000.0)]))
         tag = f'fused case {c} pre={pre} slots={len(kinds)} B={B} chans={chans}/{n_total} w={weights} td={len(tdw)} fcut={fcut_c}'
         if verbose:
             print('   searches', searches, 'windows', tdw, flush=True)
@@ -443,6 +443,8 @@ if __name__ == '__main__':
         bad = run_fused(cases, seed, n=4096)
     elif len(sys.argv) > 3 and sys.argv[3] == 'wave2':         # k_wave2, 8192 samples
         bad = run_fused(cases, seed, n=8192)
+    elif len(sys.argv) > 3 and sys.argv[3] == 'wave4':         # k_wave2 with four waves, 16384 samples
+        bad = run_fused(cases, seed, n=16384)
     elif len(sys.argv) > 3 and sys.argv[3] == 'adc':
         bad = run_adc(cases, seed)
     else:
