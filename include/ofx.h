@@ -38,13 +38,13 @@ enum { OFX_MEM_HOST = 0, OFX_MEM_DEVICE = 1 };
 /* engines: FUSED = one persistent LDS-resident FFT kernel per trace
  *          ROCFFT = rocFFT R2C -> filter kernel -> rocFFT C2R -> arg-max kernel
  *          AUTO = FUSED where the trace length is supported, else ROCFFT     */
-enum { OFX_ENGINE_AUTO = 0,     /* FUSED if n_samples is 32768, 25000, 20000, 12500, 8192 or 4096, else LDS if it applies, else ROCFFT */
+enum { OFX_ENGINE_AUTO = 0,     /* FUSED if n_samples is 32768, 25000, 20000, 16384, 12500, 8192 or 4096, else LDS if it applies, else ROCFFT */
        OFX_ENGINE_FUSED = 1,    /* register/LDS-resident kernels: n_samples == 32768 (k_fused),
                                    25000 and 12500 (k_fused25 / k_fused12: the 20 ms and 10 ms traces
                                    of the reference's examples at 1.25 MHz), 20000 (k_fused20) and
-                                   4096 / 8192 (k_wave / k_wave2, one / two waves per trace); lowchi2
+                                   4096 / 8192 / 16384 (k_wave / k_wave2, one / two / four waves per trace); lowchi2
                                    cut-offs and psd_amp bands up to 62 kHz = 1250 / 1000 / 625 bins (4096 /
-                                   8192 samples: 256 / 512 bins = 78 kHz), beyond that AUTO plans fall back */
+                                   8192 / 16384 samples: 256 / 512 / 1024 bins = 78 kHz), beyond that AUTO plans fall back */
        OFX_ENGINE_ROCFFT = 2,   /* rocFFT pipeline, any even n_samples                         */
        OFX_ENGINE_LDS = 3 };    /* LDS-resident kernel, n_samples/2 = 2^a 3^b 5^c, <= 34816    */
 
@@ -134,7 +134,7 @@ int ofx_plan_set_filter(ofx_plan* plan, int slot, const double* wf,
  * lowchi2_fcutoff: bins with |f_k| <= cutoff enter lowchi2.  Engine limits on that count
  * (checked at ofx_process, OFX_ERR_UNSUPPORTED; an OFX_ENGINE_AUTO plan then runs the call on
  * the LDS engine where that one carries the length, else on the ROCFFT engine): FUSED 4096 bins
- * (156 kHz at 32768 samples / 1.25 MHz; 1250 / 1000 / 625 / 512 / 256 bins at 25000 / 20000 / 12500 / 8192 / 4096; the reference
+ * (156 kHz at 32768 samples / 1.25 MHz; 1250 / 1000 / 1024 / 625 / 512 / 256 bins at 25000 / 20000 / 16384 / 12500 / 8192 / 4096; the reference
  * example's 50 kHz = 1311 bins, examples/processing/process_example.yaml:113), LDS 1024 bins,
  * ROCFFT none.  The same limits hold for the upper bin of ofx_plan_add_band.
  * Returns the search id (>= 0) or a negative error.

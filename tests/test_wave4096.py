@@ -1,7 +1,7 @@
 """GPU parity tests of the one-wave-per-trace kernel for 4096-sample traces (BASELINE configs[0]'s
 trace length; detprocess_amd/csrc/ofx_wave.hip): k_wave through the C ABI against the fp64 oracle,
 and the LDS engine on the same inputs (the golden fixtures of this length: tests/test_golden.py).
-Every test also runs at 8192 samples: the two-waves-per-trace kernel k_wave2 (ofx_wave2.hip)."""
+Every test also runs at 8192 and 16384 samples: k_wave2 (ofx_wave2.hip) with two / four waves per trace."""
 import numpy as np
 import pytest
 
