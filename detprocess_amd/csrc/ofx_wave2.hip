@@ -4,32 +4,31 @@
 // maximum / minimum / psd_amp on 8192- and 16384-sample traces (detprocess/core/algorithms.py:277-570, 650-885,
 // 952-1044; processing_data.py:712-772), as ofx_wave.hip does at 4096 samples.
 //
-// The packed transform has M' = 4096 complex points; it is split once, decimation in frequency, into two
-// 2048-point transforms -- exactly the transform a wave of ofx_wave.hip runs in its registers:
+// W waves per trace (W = 2: 8192 samples, W = 4: 16384).  The packed transform has M' = 2048 W complex points;
+// it is split once, decimation in frequency, into W transforms of 2048 points -- exactly the transform a wave of
+// ofx_wave.hip runs in its registers:
 //
-//   y_s[m] = (z[m] + (-1)^s z[m + 2048]) w_4096^{m s},  s = 0, 1      X[2 q + s] = FFT_2048(y_s)[q]
+//   y_s[m] = (sum_j z[m + 2048 j] e^{-2 pi i s j / W}) w_M'^{m s},  s = 0 .. W-1      X[W q + s] = FFT_2048(y_s)[q]
 //
-// Wave s of the workgroup loads BOTH halves of the trace (the second read of a line is an L2 hit), forms y_s
-// in its registers and owns the bins of parity s from there on: F1 / E1 / F2 / E2 / F3 of ofx_wave_parts.h,
-// no workgroup barrier, no exchange with the other wave.  The Hermitian partner of bin 2 q + s is
-// M' - (2 q + s) = 2 (2048 - q) [s = 0] or 2 (2047 - q) + 1 [s = 1]: the SAME parity, so the pairwise
-// middle step stays inside the wave as well (even wave: the layout of k_wave, DC / Nyquist and the
-// self-paired bin M'/2 in lane 0; odd wave: blocks v and 127 - v, nothing self-paired).  The inverse mirrors
-// the forward; only then do the waves meet:
+// Wave s loads its own part z[m + 2048 s] (and sums the time-domain windows over it); the parts meet through
+// the waves' exchange buffers in LDS, every wave combining them at its own (lane, register), and from there
+// on wave s owns the bins of residue s: F1 / E1 / F2 / E2 / F3 of ofx_wave_parts.h, no barrier, no exchange.
+// The Hermitian partner of bin W q + s is M' - (W q + s) = W (2048 - q) [s = 0] or W (2047 - q) + (W - s):
+//   s = 0      pairs inside the wave: the layout of k_wave, DC / Nyquist and the self-paired bin M'/2 in lane 0
+//   s = W / 2  pairs inside the wave: blocks v and 127 - v, nothing self-paired
+//   s = 1, 3 (W = 4)  cross: lane v of wave 1 holds the blocks v and 127 - v of its bins and needs block 127 - v
+//              of wave 3 -- the partner half of wave 3's lane v.  The two waves swap the partner halves of their
+//              lanes through LDS before the middle step and swap the results back after it (lane to lane, row
+//              stride 17, three workgroup barriers); their partners' low bins go to the other wave's stash.
+// The inverse mirrors the forward; then the waves meet again,
 //
-//   A(2 m + e), A(4096 + 2 m + e) = Re / Im of  y'_0[m] +- conj(w_4096^m) y'_1[m]
+//   A(2 m + e + 4096 j) = Re / Im of  sum_s conj(w_M'^{m s}) y'_s[m] e^{+2 pi i s j / W}
 //
-// through each other's exchange buffer (one barrier of two waves), after which wave s holds the lags of
-// half s.  Arg-max candidates, chi2_0, the window sums and the low-frequency chi2 are partial per wave and
-// meet in a few words of LDS; wave 0 writes the row.  Four workgroups per CU: eight waves, four traces in
-// flight.  The next trace is requested into the 128 registers of the two raw halves as soon as the lags
-// have been reduced / dumped.
-//
-// W = 4 (16384 samples, four waves per trace): the same with a radix-4 split,
-//   y_s[m] = (sum_j z[m + 2048 j] (-i)^{s j}) w_8192^{m s},   X[4 q + s] = FFT_2048(y_s)[q],
-// each wave loading its own quarter and the quarters meeting through LDS (the mirror image of the inverse side).  The partners of the bins 4 q + 1 are
-// the bins 4 (2047 - q) + 3: the waves 1 and 3 swap the partner halves of their lanes through LDS before
-// and after the middle step (lane to lane, two more barriers); the waves 0 and 2 pair inside themselves.
+// and wave j holds the lags of part j.  Arg-max candidates, chi2_0, the window sums, the band sums and the
+// low-frequency chi2 (wave s owns the bins of residue s) are partial per wave and meet in a few words of LDS,
+// double-buffered by trace parity; windowed searches scan the dump of all parts; wave 0 writes the row.  One
+// trace per workgroup, eight waves per CU.  The next trace's part is requested into 64 registers as soon as the
+// lags have been reduced / dumped.
 //
 // Roofline: HBM, N x 4 + 16 B algorithmic per trace.
 #include <cmath>
@@ -195,11 +194,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
         const OfxSearchDev& sq = sd.search[q];
         any_full |= (sq.kind == OFX_SEARCH_DELAY) && !sq.outside && sq.lo == 0 && sq.hi == VN;
     }
-    // the raw parts of the trace, m = 128 n1 + lane + 64 h:  W = 2: a = z[m], bq = z[m + 2048], both in both
-    // waves (the second read of a line is an L2 hit); W = 4: a = z[m + 2048 s], the wave's own quarter -- the
-    // quarters meet through LDS (four readers per line were four HBM reads: 328 KB of traffic per 64 KB trace)
+    // the wave's own part of the trace, a = z[m + 2048 s], m = 128 n1 + lane + 64 h: the parts meet through LDS
+    // (every wave reading the whole trace was tried first: four readers per line were four HBM reads at W = 4,
+    // 328 KB of traffic per 64 KB trace; at W = 2 the second read hit L2 and the two forms run at the same rate)
     cpx a[WNV];
-    [[maybe_unused]] cpx bq[WNV];
     cpx d[WNV];
     auto load_part = [&](cpx (&z)[WNV], const float* chan, int part) {
         const __amdgpu_buffer_rsrc_t rz = make_rsrc(chan, VN * 4);
@@ -209,19 +207,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
             for (int n1 = 0; n1 < 16; ++n1) z[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + part * 16384);
     };
     auto request = [&](long long bb) {
-        const float* e = traces + (size_t)bb * ev_stride + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0);
-        if constexpr (W == 2) {
-            const __amdgpu_buffer_rsrc_t rz = make_rsrc(e, VN * 4);
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int n1 = 0; n1 < 16; ++n1) {
-                    a[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024);
-                    bq[16 * h + n1] = buf_ld2(rz, (lane + 64 * h) * 8, n1 * 1024 + 16384);
-                }
-        } else {
-            load_part(a, e, s);             // four waves: each loads its own quarter, once
-        }
+        load_part(a, traces + (size_t)bb * ev_stride + ((FEAT & 4) ? (size_t)pd.chan[0] * VN : 0), s);
     };
     // channel algebra on one part (FEAT bit 2): weight of the first term, then the other terms
     [[maybe_unused]] auto combine_part = [&](cpx (&z)[WNV], long long bb, int part) {
@@ -271,12 +257,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
         Wave2X<W>& X = SH.x[par];
         // ------------------------------------------------ channel algebra
         if constexpr (FEAT & 4) {
-            if constexpr (W == 2) {
-                combine_part(a, bcur, 0);
-                combine_part(bq, bcur, 1);
-            } else {
-                combine_part(a, bcur, s);
-            }
+            combine_part(a, bcur, s);
         }
         // ------------------------------------------------ time-domain windows
         // wave s sums over its part of the samples: index 4096 s + 256 n1 + 2 (lane + 64 h) + {0, 1}, rows
@@ -340,14 +321,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                 }
             }
         };
-        if constexpr (FEAT & 2) {
-            if constexpr (W == 2) {
-                if (s == 0) td_sums(a);
-                else td_sums(bq);
-            } else {
-                td_sums(a);
-            }
-        }
+        if constexpr (FEAT & 2) td_sums(a);
         // one lane of wave 0 per window: the partials, the end points, the eight values
         auto td_finalize = [&]() {
             if constexpr (FEAT & 2) {
@@ -387,7 +361,7 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
             }
         };
         // ---------------------------------------------------------------- the split: y_s
-        if constexpr (W == 2) {
+        {
             if (sd.n_search == 0) {                     // windows only
                 __syncthreads();
                 td_finalize();
@@ -398,35 +372,29 @@ __global__ __launch_bounds__(64 * W, 2) void k_wave2(OfxPlanDev pd, OfxSlotDev s
                 vcur = vnext;
                 continue;
             }
-            if (s == 0) {
-#pragma unroll
-                for (int j = 0; j < WNV; ++j) d[j] = a[j] + bq[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < WNV; ++j) d[j] = a[j] - bq[j];
-            }
-        } else {
-            if (sd.n_search == 0) {                     // windows only
-                __syncthreads();
-                td_finalize();
-                if (have_next) {
-                    if (valid) vnext = valid[bnext];
-                    request(bnext);
-                }
-                vcur = vnext;
-                continue;
-            }
-            // the quarters meet: y_s before its twiddle = sum_j z_j (-i)^{s j}, every wave at its own (lane, register)
+            // the parts meet: y_s before its twiddle = sum_j z_j (-i)^{s j} (W = 2: z_0 +- z_1), every wave at its own
+            // (lane, register)
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int n1 = 0; n1 < 16; ++n1) xc[128 * n1 + lane + 64 * h] = a[16 * h + n1];
             __syncthreads();
-            {
+            if constexpr (W == 2) {
                 const cpx* const x0 = SH.w[0].xb;
                 const cpx* const x1 = SH.w[1].xb;
-                const cpx* const x2 = SH.w[2].xb;
-                const cpx* const x3 = SH.w[3].xb;
+                const float sg = s ? -1.0f : 1.0f;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int n1 = 0; n1 < 16; ++n1) {
+                        const int m = 128 * n1 + lane + 64 * h;
+                        d[16 * h + n1] = pfma(x1[m], mk(sg, sg), x0[m]);
+                    }
+            } else {
+                const cpx* const x0 = SH.w[0].xb;
+                const cpx* const x1 = SH.w[1].xb;
+                const cpx* const x2 = SH.w[W - 2].xb;
+                const cpx* const x3 = SH.w[W - 1].xb;
                 const float sg = (s & 1) ? -1.0f : 1.0f;    // (-i)^{2 s}
                 const float sr = (s & 2) ? -1.0f : 1.0f;
 #pragma unroll
