@@ -401,6 +401,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     FusedLds& L = reinterpret_cast<FusedLds*>(smem_raw + sizeof(FusedShared))[half];
     const int tid = PP ? (int)(threadIdx.x & (FT - 1)) : (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     // slot barrier of the ping-pong schedule inside a register-arithmetic phase (see exchange)
 #define PPB()                                  \
     do {                                       \
@@ -549,8 +550,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     // 4-channel plan waited for every load in turn: 72 k cycles per trace in the timeline of
     // BASELINE configs[3]).  The arithmetic is unchanged: w0 s0, then fma(w_c, s_c, .) in order.
     auto load_trace = [&](long long bb) __attribute__((always_inline)) {
-        int tl = tid;
-        asm volatile("" : "+v"(tl));
+        int tl = ofx_fresh_tid(wave_base);
         const float* e = traces + (size_t)bb * ev_stride;
         const __amdgpu_buffer_rsrc_t rz =
             make_rsrc(e + ((FEAT & 4) ? (size_t)pd.chan[0] * FN : 0), FN * 4);
@@ -563,8 +563,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     auto combine_terms = [&](long long bb) __attribute__((always_inline)) {
         if constexpr (FEAT & 4) {
             if (pd.n_terms == 1 && pd.weight[0] == 1.0f) return;         // uniform: a plain select
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
+            int tl = ofx_fresh_tid(wave_base);
             const float* e = traces + (size_t)bb * ev_stride;
             const float w0 = pd.weight[0];
 #pragma unroll
@@ -587,8 +586,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
     const __amdgpu_buffer_rsrc_t rspec =
         make_rsrc(spec + (MULTI ? (size_t)wg * NV * FT : 0), NV * FT * 8);
     auto store_spec = [&]() __attribute__((always_inline)) {
-        int tl = tid;
-        asm volatile("" : "+v"(tl));
+        int tl = ofx_fresh_tid(wave_base);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             u32x2 v;
@@ -598,8 +596,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         }
     };
     auto load_spec = [&]() __attribute__((always_inline)) {
-        int tl = tid;
-        asm volatile("" : "+v"(tl));
+        int tl = ofx_fresh_tid(wave_base);
 #pragma unroll
         for (int j = 0; j < NV; ++j) d[j] = buf_ld2(rspec, tl * 8, j * FT * 8);
     };
@@ -653,8 +650,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         }
         // Roles are re-derived from an opaque copy of tid every trace so that the LDS
         // address arithmetic stays next to its use (LICM would hoist and spill it).
-        int tl = tid;
-        asm volatile("" : "+v"(tl));
+        int tl = ofx_fresh_tid(wave_base);
         const Roles R0(tl), R1(tl + FT);
         auto RR = [&](int h) -> const Roles& { return h == 0 ? R0 : R1; };
 
@@ -857,8 +853,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         __builtin_amdgcn_s_setprio(0);
 #endif
         STAMP(6);                                // F3 + middle + I3
-        int tl2 = tid;
-        asm volatile("" : "+v"(tl2));          // no CSE of addresses across the middle
+        int tl2 = ofx_fresh_tid(wave_base);          // no CSE of addresses across the middle
         const Roles Q0(tl2), Q1(tl2 + FT);
         auto QQ = [&](int h) -> const Roles& { return h == 0 ? Q0 : Q1; };
         exchange([&](int h, int j) { return QQ(h).e2r(j); }, [](int, int j) { return j >> 4; },
@@ -917,8 +912,7 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         // ------------------------------------------------------------- tail
         // (thread ids of the tail come from an opaque copy: its LDS / table addresses are
         // recomputed here instead of being hoisted out of the loop and spilled)
-        int tt = tid;
-        asm volatile("" : "+v"(tt));
+        int tt = ofx_fresh_tid(wave_base);
         const int lane_t = tt & 63, wave_t = tt >> 6;
         const __amdgpu_buffer_rsrc_t rs_s = make_rsrc(SDX.s, NLOW_MAX * 8);
         const __amdgpu_buffer_rsrc_t rs_g = make_rsrc(SDX.g, NLOW_MAX * 4);

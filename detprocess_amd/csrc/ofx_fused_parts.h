@@ -27,6 +27,15 @@ __device__ __forceinline__ cpx buf_ld2(__amdgpu_buffer_rsrc_t r, int voff, int s
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
     return mk(__uint_as_float(v.x), __uint_as_float(v.y));
 }
+// The thread index from scratch-free sources: 64 x wave (a scalar) + the lane count of v_mbcnt.  The phases of the
+// kernels re-derive their addresses from a fresh copy of the thread index (so that LICM does not hoist and spill
+// them); taking that copy from the live `tid` kept `tid` itself in a spill slot, reloaded -- behind an s_waitcnt
+// vmcnt(0) -- six times per trace, once in front of the 64 loads of the next trace.
+__device__ __forceinline__ int ofx_fresh_tid(int wave_base) {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return wave_base + l;
+}
 __device__ __forceinline__ cpx lo2(const float4& q) { return mk(q.x, q.y); }
 __device__ __forceinline__ cpx hi2(const float4& q) { return mk(q.z, q.w); }
 __device__ __forceinline__ cpx cconj(cpx z) { return z * mk(1.0f, -1.0f); }
