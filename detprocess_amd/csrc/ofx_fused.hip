@@ -206,7 +206,12 @@ __device__ __forceinline__ cpx perm_out(cpx (&d)[NV], bool z, cpx a8, const Fuse
     if (z) {
         // self-paired bin k = M/2 (A0[8]):  X = conj(Z), Z' = 2 conj(W) Z
         const cpx zq = cmulc(a8, mk(tabs.wq.x, tabs.wq.y));
-        chi = pfma(a8 * a8, mk(2.0f * tabs.gq, 2.0f * tabs.gq), chi);
+        // (2 g from the scalar argument, behind an opaque copy: as a loop-invariant vector pair it was
+        // spilled before the loop and reloaded here)
+        int gqi = __float_as_int(tabs.gq);
+        asm volatile("" : "+s"(gqi));
+        const float g2 = 2.0f * __int_as_float(gqi);
+        chi = pfma(a8 * a8, mk(g2, g2), chi);
 #pragma unroll
         for (int j = 0; j < 32; ++j) buf[j] = d[O + j];
 #pragma unroll
@@ -849,6 +854,12 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
             dft<16, +1, NV, O + 16>(d);
         }
         const float chi0p = chi2v.x + chi2v.y;
+        // (the wave's share of chi2_0 goes to LDS here: carried to the tail in a register it was spilled
+        // across the inverse transform and reloaded behind an s_waitcnt vmcnt(0))
+        {
+            const float wchi = ofx_wave_sum(chi0p);
+            if (lane == 0) L.red[1][wave_base >> 6] = wchi;     // (scalar index: no address register to keep)
+        }
 #if OFX_MPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -945,12 +956,8 @@ __global__ __launch_bounds__(BLOCK_THREADS, (BLOCK_THREADS / 256) * WG_PER_CU) v
         TSTAMP(2);                               // group maxima, table requests
         {
             const float wmax = ofx_wave_max(mloc);
-            const float wchi = ofx_wave_sum(chi0p);
             __syncthreads();
-            if (lane_t == 0) {
-                L.red[0][wave_t] = wmax;
-                L.red[1][wave_t] = wchi;
-            }
+            if (lane_t == 0) L.red[0][wave_t] = wmax;
             if (tt == 0) L.bcast[0] = d[0].x;          // A(lag 0) for nodelay
             __syncthreads();
         }
